@@ -1,0 +1,239 @@
+"""ctypes binding of libgs3d_hip.so (include/gs3d_hip.h) for tests and bench.py.
+
+Host-language note: the reference is a C++ library, so the host-side mirror of its API is C++
+(csrc/host/, include/3dgs/).  This module is only the Python harness over the same C ABI: it adds
+no arithmetic and never falls back to a CPU path -- if the HIP library or a GPU is missing, calls
+raise GsError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgs3d_hip.so")
+
+UNIFORMS_DT = np.dtype([("camera_position", "<f4", 4), ("proj_mat", "<f4", 16), ("view_mat", "<f4", 16),
+                        ("width", "<u4"), ("height", "<u4"), ("tan_fovx", "<f4"), ("tan_fovy", "<f4")])
+CAMERA_DT = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("fov", "<f4"),
+                      ("near_plane", "<f4"), ("far_plane", "<f4")])
+VERTEX_FLOATS = 60
+RECORD_FLOATS = 62
+BLOB_PLANES = 59
+
+STAGES = dict(tiles=(0, np.uint32), depth=(1, np.float32), radius=(2, np.float32), aabb=(3, np.uint16),
+              conic_opacity=(4, np.float32), uv_rg=(5, np.float32), b=(6, np.float32),
+              depth_order=(7, np.uint32), offsets=(8, np.uint32), instance_tile=(9, np.uint32),
+              instance_gid=(10, np.uint32), sorted_tile=(11, np.uint32), sorted_gid=(12, np.uint32),
+              ranges=(13, np.uint32))
+
+# every symbol include/gs3d_hip.h declares
+SYMBOLS = ["gs_last_error", "gs_device_count", "gs_scene_load_ply", "gs_scene_from_records",
+           "gs_scene_from_vertices", "gs_scene_from_device_blob", "gs_scene_blob_floats", "gs_scene_blob",
+           "gs_scene_num_vertices", "gs_scene_download_vertices", "gs_scene_download_cov3d",
+           "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
+           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_debug_taps",
+           "gs_get_stats", "gs_debug_download", "gs_renderer_stream"]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("num_gaussians", C.c_uint64), ("num_visible", C.c_uint64), ("num_instances", C.c_uint64),
+                ("instance_capacity", C.c_uint64), ("ms_preprocess", C.c_float), ("ms_prefix_sum", C.c_float),
+                ("ms_preprocess_sort", C.c_float), ("ms_sort", C.c_float), ("ms_tile_boundary", C.c_float),
+                ("ms_render", C.c_float), ("ms_total", C.c_float), ("retries", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class GsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+_LIB = None
+
+
+def lib():
+    """Load libgs3d_hip.so; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GsError(-3, f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950)")
+        L = C.CDLL(LIB_PATH)
+        L.gs_last_error.restype = C.c_char_p
+        L.gs_scene_num_vertices.restype = C.c_uint64
+        L.gs_scene_num_vertices.argtypes = [C.c_void_p]
+        L.gs_scene_blob_floats.restype = C.c_uint64
+        L.gs_scene_blob_floats.argtypes = [C.c_uint64]
+        L.gs_renderer_stream.restype = C.c_void_p
+        L.gs_renderer_stream.argtypes = [C.c_void_p]
+        L.gs_scene_destroy.argtypes = [C.c_void_p]
+        L.gs_renderer_destroy.argtypes = [C.c_void_p]
+        L.gs_scene_destroy.restype = None
+        L.gs_renderer_destroy.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise GsError(rc, lib().gs_last_error().decode(errors="replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().gs_device_count(C.byref(n)))
+    return n.value
+
+
+def make_camera(position=(0, 0, 0), rotation=(1, 0, 0, 0), fov=45.0, near=0.1, far=1000.0):
+    """Renderer::Camera with the reference defaults (Renderer.h:79-85)."""
+    cam = np.zeros(1, CAMERA_DT)
+    cam["position"] = position
+    cam["rotation"] = rotation
+    cam["fov"], cam["near_plane"], cam["far_plane"] = fov, near, far
+    return cam
+
+
+def camera_uniforms(cam, width, height):
+    out = np.zeros(1, UNIFORMS_DT)
+    _check(lib().gs_camera_uniforms(_p(cam), C.c_uint32(width), C.c_uint32(height), _p(out)))
+    return out
+
+
+class Scene:
+    """GSScene counterpart (SoA in HBM)."""
+
+    def __init__(self, handle, keepalive=None):
+        self._h = handle
+        self._keepalive = keepalive
+
+    @classmethod
+    def load_ply(cls, path, device=0):
+        h = C.c_void_p()
+        _check(lib().gs_scene_load_ply(os.fsencode(path), C.c_int(device), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_records(cls, records, device=0):
+        records = np.ascontiguousarray(records, np.float32).reshape(-1, RECORD_FLOATS)
+        h = C.c_void_p()
+        _check(lib().gs_scene_from_records(_p(records), C.c_uint64(len(records)), C.c_int(device), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_vertices(cls, vertices, device=0):
+        """vertices: (n, 60) float32 or the structured GSScene::Vertex array."""
+        v = np.ascontiguousarray(vertices).view(np.float32).reshape(-1, VERTEX_FLOATS)
+        h = C.c_void_p()
+        _check(lib().gs_scene_from_vertices(_p(v), C.c_uint64(len(v)), C.c_int(device), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_device_blob(cls, ptr, n, device=0, keepalive=None):
+        h = C.c_void_p()
+        _check(lib().gs_scene_from_device_blob(C.c_void_p(ptr), C.c_uint64(n), C.c_int(device), C.byref(h)))
+        return cls(h, keepalive)
+
+    @property
+    def num_vertices(self):
+        return lib().gs_scene_num_vertices(self._h)
+
+    def blob(self):
+        """(device pointer, float count) of the packed SoA blob."""
+        p = C.c_void_p()
+        n = C.c_uint64()
+        _check(lib().gs_scene_blob(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def download_vertices(self):
+        out = np.zeros((self.num_vertices, VERTEX_FLOATS), np.float32)
+        _check(lib().gs_scene_download_vertices(self._h, _p(out)))
+        return out
+
+    def download_cov3d(self):
+        out = np.zeros((self.num_vertices, 6), np.float32)
+        _check(lib().gs_scene_download_cov3d(self._h, _p(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().gs_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Renderer:
+    """Renderer counterpart: one stream, one frame in flight."""
+
+    def __init__(self, scene):
+        self.scene = scene
+        self._h = C.c_void_p()
+        _check(lib().gs_renderer_create(scene._h, C.byref(self._h)))
+
+    def render(self, uniforms, rgba_ptr=0, bgra_ptr=0):
+        """Enqueue one frame into device buffers (raw pointers, e.g. tensor.data_ptr())."""
+        _check(lib().gs_render(self._h, _p(uniforms), C.c_void_p(rgba_ptr), C.c_void_p(bgra_ptr)))
+
+    def render_host(self, uniforms, want_rgba=True, want_bgra=False):
+        h, w = int(uniforms["height"][0]), int(uniforms["width"][0])
+        rgba = np.zeros((h, w, 4), np.float32) if want_rgba else None
+        bgra = np.zeros((h, w, 4), np.uint8) if want_bgra else None
+        _check(lib().gs_render_host(self._h, _p(uniforms), _p(rgba) if want_rgba else None,
+                                    _p(bgra) if want_bgra else None))
+        return rgba, bgra
+
+    def synchronize(self):
+        _check(lib().gs_synchronize(self._h))
+
+    def set_timing(self, enabled):
+        _check(lib().gs_set_timing(self._h, C.c_int(int(enabled))))
+
+    def set_debug_taps(self, enabled):
+        _check(lib().gs_set_debug_taps(self._h, C.c_int(int(enabled))))
+
+    def stats(self):
+        st = FrameStats()
+        _check(lib().gs_get_stats(self._h, C.byref(st)))
+        return st
+
+    def stage(self, name, uniforms=None):
+        """Download a stage buffer of the last frame as a numpy array."""
+        code, dt = STAGES[name]
+        st = self.stats()
+        n, v, d = st.num_gaussians, st.num_visible, min(st.num_instances, st.instance_capacity)
+        count = {"tiles": n, "depth": n, "radius": n, "aabb": 4 * n, "conic_opacity": 4 * n, "uv_rg": 4 * n,
+                 "b": n, "depth_order": v, "offsets": v, "instance_tile": d, "instance_gid": d,
+                 "sorted_tile": d, "sorted_gid": d}.get(name)
+        if name == "ranges":
+            w, h = int(uniforms["width"][0]), int(uniforms["height"][0])
+            count = 2 * ((w + 15) // 16) * ((h + 15) // 16)
+        out = np.zeros(max(int(count), 1), dt)
+        _check(lib().gs_debug_download(self._h, C.c_int(code), _p(out), C.c_uint64(int(count) * out.itemsize)))
+        return out[:int(count)]
+
+    @property
+    def stream(self):
+        return lib().gs_renderer_stream(self._h)
+
+    def close(self):
+        if self._h:
+            lib().gs_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

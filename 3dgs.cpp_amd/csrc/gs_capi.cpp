@@ -1,0 +1,642 @@
+// gs_capi.cpp -- scene / renderer objects and the C ABI of include/gs3d_hip.h.
+//
+// Frame orchestration replaces Renderer::recordPreprocessCommandBuffer / recordRenderCommandBuffer /
+// draw (src/Renderer.cpp:468-529, 532-717, 366-426): every pass is enqueued on one HIP stream with
+// grids that do not depend on the data-dependent counts V (visible) and D (instances); the counts
+// live in device memory, so the reference's mid-frame fence wait + 4-byte readback + command-buffer
+// re-record (Renderer.cpp:391-399, 538) disappears.  D is copied back asynchronously at the end of
+// the frame only to detect instance-buffer overflow (Renderer.cpp:541-563 grows and retries too).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gs_host_math.h"
+#include "gs_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_CHECK(expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            throw Error(GS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return GS_OK;
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_last_error = "out of host memory";
+        return GS_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return GS_ERR_INVALID;
+    }
+}
+
+void select_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        throw Error(GS_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= count) throw Error(GS_ERR_INVALID, "device index out of range");
+    HIP_CHECK(hipSetDevice(device));
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, count * sizeof(T));
+        if (e != hipSuccess) throw Error(GS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        p = static_cast<T*>(q);
+        n = count;
+    }
+    void ensure(size_t count) {
+        if (count > n) alloc(count);
+    }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// gs_scene: SoA scene in HBM (59 planes) + cov3D (6 planes).  Replaces GSScene's AoS
+// vertexBuffer (240 B / Gaussian) and cov3DBuffer.
+// ------------------------------------------------------------------------------------------
+struct gs_scene {
+    int device = 0;
+    uint64_t n = 0;
+    DevBuf<float> owned_blob;
+    float* blob = nullptr;  // owned_blob.p or adopted
+    DevBuf<float> cov3d;
+
+    void finish_load() {  // GSScene::precomputeCov3D, GSScene.cpp:157-184
+        cov3d.alloc(6 * n);
+        gs::launch_cov3d(blob, cov3d.p, static_cast<uint32_t>(n), nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
+};
+
+namespace {
+
+constexpr uint64_t kMaxGaussians = 1ull << 31;  // ids and counts are 32-bit on the device
+
+void upload_vertices(gs_scene* s, const float* vertices, uint64_t n) {
+    // AoS GSScene::Vertex[n] -> 59 SoA planes (pos3, scale3, rot4, opacity, sh48)
+    if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
+    s->n = n;
+    std::vector<float> planes(static_cast<size_t>(gs::P_COUNT) * n);
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* v = vertices + i * gs::host::kVertexFloats;
+        for (int k = 0; k < 3; ++k) planes[(gs::P_POS + k) * n + i] = v[k];
+        for (int k = 0; k < 3; ++k) planes[(gs::P_SCALE + k) * n + i] = v[4 + k];
+        for (int k = 0; k < 4; ++k) planes[(gs::P_ROT + k) * n + i] = v[8 + k];
+        planes[static_cast<size_t>(gs::P_OPACITY) * n + i] = v[7];
+        for (int k = 0; k < 48; ++k) planes[(gs::P_SH + k) * n + i] = v[12 + k];
+    }
+    s->owned_blob.alloc(planes.size());
+    s->blob = s->owned_blob.p;
+    if (n) HIP_CHECK(hipMemcpy(s->blob, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
+    s->finish_load();
+}
+
+void activate_and_upload(gs_scene* s, const float* records, uint64_t n) {
+    std::vector<float> verts(static_cast<size_t>(n) * gs::host::kVertexFloats);
+    for (uint64_t i = 0; i < n; ++i)
+        gs::host::activate_record(records + i * gs::host::kRecordFloats, verts.data() + i * gs::host::kVertexFloats);
+    upload_vertices(s, verts.data(), n);
+}
+
+// GSScene::loadPlyHeader, GSScene.cpp:99-149: format, element vertex N, end_header.
+std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw Error(GS_ERR_IO, "File does not exist: " + path);
+    std::string line;
+    long long n = -1;
+    bool header_end = false;
+    while (std::getline(f, line)) {
+        std::istringstream iss(line);
+        std::string token;
+        iss >> token;
+        if (token == "element") {
+            iss >> token;
+            if (token == "vertex") iss >> n;
+        } else if (token == "end_header") {
+            header_end = true;
+            break;
+        }
+    }
+    if (!header_end) throw Error(GS_ERR_IO, "Could not find end of header");
+    if (n < 0) throw Error(GS_ERR_IO, "PLY header has no 'element vertex'");
+    std::vector<float> rec(static_cast<size_t>(n) * gs::host::kRecordFloats);
+    f.read(reinterpret_cast<char*>(rec.data()), static_cast<std::streamsize>(rec.size() * sizeof(float)));
+    if (static_cast<size_t>(f.gcount()) != rec.size() * sizeof(float))
+        throw Error(GS_ERR_IO, "PLY payload is shorter than 'element vertex' x 62 floats: " + path);
+    *n_out = static_cast<uint64_t>(n);
+    return rec;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// gs_renderer
+// ------------------------------------------------------------------------------------------
+struct gs_renderer {
+    gs_scene* scene = nullptr;
+    hipStream_t stream = nullptr;
+    bool timing = true;
+    bool keep_taps = false;  // debug: preserve the pre-sort instance arrays for gs_debug_download
+    DevBuf<uint32_t> tap_tile, tap_gid;
+
+    // per-Gaussian attributes
+    DevBuf<uint32_t> tiles;
+    DevBuf<float> depth, radius, bch;
+    DevBuf<ushort4> aabb;
+    DevBuf<float4> conic_op, uv_rg;
+    // depth sort
+    DevBuf<uint32_t> dkeys[2], dvals[2], tiles_sorted, offsets;
+    DevBuf<uint32_t> block_hist, digit_total, scan_partial;
+    // instances
+    uint32_t capacity = 0;
+    DevBuf<uint32_t> ikeys[2], ivals[2];
+    DevBuf<uint32_t> ranges;
+    DevBuf<gs::Counters> counters;
+    gs::Counters* h_counters = nullptr;  // pinned
+
+    hipEvent_t ev[8] = {};
+    // last frame (for overflow retry and taps)
+    gs_uniforms last_u{};
+    float* last_rgba = nullptr;
+    uint8_t* last_bgra = nullptr;
+    bool frame_pending = false;
+    bool have_frame = false;
+    uint32_t retries = 0;
+    uint32_t* sorted_tile = nullptr;  // result buffers of the last frame
+    uint32_t* sorted_gid = nullptr;
+    uint32_t* inst_tile = nullptr;
+    uint32_t* inst_gid = nullptr;
+    uint32_t* depth_order = nullptr;
+    uint64_t num_tiles = 0;
+
+    ~gs_renderer() {
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (h_counters) (void)hipHostFree(h_counters);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    void set_capacity(uint32_t cap) {
+        capacity = cap;
+        for (int k = 0; k < 2; ++k) {
+            ikeys[k].alloc(cap);
+            ivals[k].alloc(cap);
+        }
+    }
+
+    void init() {
+        HIP_CHECK(hipSetDevice(scene->device));
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+        const size_t n = scene->n;
+        tiles.alloc(n);
+        depth.alloc(n);
+        radius.alloc(n);
+        bch.alloc(n);
+        aabb.alloc(n);
+        conic_op.alloc(n);
+        uv_rg.alloc(n);
+        for (int k = 0; k < 2; ++k) {
+            dkeys[k].alloc(n);
+            dvals[k].alloc(n);
+        }
+        tiles_sorted.alloc(n);
+        offsets.alloc(n);
+        block_hist.alloc(256 * static_cast<size_t>(gs::kSortMaxBlocks));
+        digit_total.alloc(256);
+        scan_partial.alloc(gs::kScanBlocks);
+        counters.alloc(1);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters), sizeof(gs::Counters), hipHostMallocDefault));
+        *h_counters = gs::Counters{};
+        const uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(n));
+        set_capacity(static_cast<uint32_t>(std::min<uint64_t>(want, 0xFFFFF000ull)));
+    }
+
+    void enqueue(const gs_uniforms& u, float* d_rgba, uint8_t* d_bgra) {
+        HIP_CHECK(hipSetDevice(scene->device));
+        const uint32_t n = static_cast<uint32_t>(scene->n);
+        const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
+        num_tiles = static_cast<uint64_t>(tx) * ty;
+        if (tx > 65535 || ty > 65535) throw Error(GS_ERR_INVALID, "resolution too large (tile box is 16-bit)");
+        ranges.ensure(2 * num_tiles);
+
+        gs::SceneView sv{scene->blob, scene->cov3d.p, n};
+        gs::AttrView av{tiles.p, depth.p, radius.p, aabb.p, conic_op.p, uv_rg.p, bch.p};
+        gs::Counters* cnt = counters.p;
+
+        HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(gs::Counters), stream));
+        HIP_CHECK(hipEventRecord(ev[0], stream));
+        gs::launch_preprocess(sv, u, av, stream);
+        if (timing) HIP_CHECK(hipEventRecord(ev[1], stream));
+
+        // ---- depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
+        {
+            const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (n + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
+            const uint32_t* kin = reinterpret_cast<const uint32_t*>(depth.p);
+            const uint32_t* vin = nullptr;
+            for (int pass = 0; pass < 4; ++pass) {
+                gs::RadixPass p{};
+                const int dst = pass & 1;
+                p.keys_in = kin;
+                p.vals_in = vin;
+                p.keys_out = dkeys[dst].p;
+                p.vals_out = dvals[dst].p;
+                p.n_in = &cnt->visible;
+                p.n_static = n;
+                p.tiles = tiles.p;
+                p.n_out = &cnt->visible;
+                p.block_hist = block_hist.p;
+                p.digit_total = digit_total.p;
+                p.shift = pass * 8;
+                p.bits = 8;
+                p.blocks = blocks;
+                p.first = pass == 0;
+                if (pass == 3) {
+                    p.gather_tiles = tiles.p;
+                    p.tiles_sorted = tiles_sorted.p;
+                }
+                gs::launch_radix_pass(p, stream);
+                kin = dkeys[dst].p;
+                vin = dvals[dst].p;
+            }
+            depth_order = dvals[1].p;
+        }
+        if (timing) HIP_CHECK(hipEventRecord(ev[2], stream));
+
+        // ---- offsets = exclusive scan of tiles_overlap in depth order; D -> counters ----
+        gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, &cnt->visible, n, scan_partial.p, &cnt->instances, stream);
+        if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
+
+        // ---- duplicate ----
+        inst_tile = ikeys[0].p;
+        inst_gid = ivals[0].p;
+        gs::launch_duplicate(depth_order, offsets.p, tiles_sorted.p, aabb.p, &cnt->visible, n, tx, capacity,
+                             inst_tile, inst_gid, cnt, stream);
+        if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
+        if (keep_taps) {  // the tile sort ping-pongs over the duplicate output
+            tap_tile.ensure(capacity);
+            tap_gid.ensure(capacity);
+            HIP_CHECK(hipMemcpyAsync(tap_tile.p, inst_tile, capacity * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(tap_gid.p, inst_gid, capacity * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            inst_tile = tap_tile.p;
+            inst_gid = tap_gid.p;
+        }
+
+        // ---- stable sort by tile id (instances are already in depth order) ----
+        {
+            int bits = 0;
+            while ((1ull << bits) < num_tiles) ++bits;
+            const int passes = (bits + 7) / 8;
+            const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (capacity + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
+            int src = 0;
+            for (int pass = 0; pass < passes; ++pass) {
+                gs::RadixPass p{};
+                p.keys_in = ikeys[src].p;
+                p.vals_in = ivals[src].p;
+                p.keys_out = ikeys[src ^ 1].p;
+                p.vals_out = ivals[src ^ 1].p;
+                p.n_in = &cnt->instances;
+                p.n_static = capacity;
+                p.block_hist = block_hist.p;
+                p.digit_total = digit_total.p;
+                p.shift = pass * 8;
+                p.bits = std::min(8, bits - pass * 8);
+                p.blocks = blocks;
+                p.first = 0;
+                gs::launch_radix_pass(p, stream);
+                src ^= 1;
+            }
+            sorted_tile = ikeys[src].p;
+            sorted_gid = ivals[src].p;
+        }
+        if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
+
+        // ---- tile ranges (Renderer.cpp:633 fill + tile_boundary) ----
+        HIP_CHECK(hipMemsetAsync(ranges.p, 0, 2 * num_tiles * sizeof(uint32_t), stream));
+        gs::launch_tile_ranges(sorted_tile, &cnt->instances, capacity, ranges.p, stream);
+        if (timing) HIP_CHECK(hipEventRecord(ev[6], stream));
+
+        // ---- blend ----
+        gs::launch_blend(ranges.p, sorted_gid, av, u.width, u.height, d_rgba, d_bgra, stream);
+        HIP_CHECK(hipEventRecord(ev[7], stream));
+        HIP_CHECK(hipMemcpyAsync(h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipGetLastError());
+
+        last_u = u;
+        last_rgba = d_rgba;
+        last_bgra = d_bgra;
+        frame_pending = true;
+        have_frame = true;
+    }
+
+    // Wait for the frame; on instance-buffer overflow grow and re-run (Renderer.cpp:541-563).
+    void finish() {
+        if (!frame_pending) return;
+        for (int attempt = 0;; ++attempt) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            frame_pending = false;
+            if (!h_counters->overflow) return;
+            if (attempt >= 4) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
+            const uint64_t need = static_cast<uint64_t>(h_counters->instances) + h_counters->instances / 8 + 4096;
+            if (need > 0xFFFFF000ull) throw Error(GS_ERR_OVERFLOW, "more than 2^32 tile instances");
+            set_capacity(static_cast<uint32_t>(need));
+            ++retries;
+            enqueue(last_u, last_rgba, last_bgra);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* gs_last_error(void) { return g_last_error.c_str(); }
+
+int gs_device_count(int* count) {
+    return guarded([&] {
+        if (!count) throw Error(GS_ERR_INVALID, "count is null");
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+        *count = c;
+    });
+}
+
+int gs_scene_load_ply(const char* path, int device, gs_scene** out) {
+    return guarded([&] {
+        if (!path || !out) throw Error(GS_ERR_INVALID, "null argument");
+        uint64_t n = 0;
+        std::vector<float> rec = read_ply(path, &n);  // IO errors first, like GSScene's ctor
+        select_device(device);
+        auto s = std::make_unique<gs_scene>();
+        s->device = device;
+        activate_and_upload(s.get(), rec.data(), n);
+        *out = s.release();
+    });
+}
+
+int gs_scene_from_records(const float* records, uint64_t n, int device, gs_scene** out) {
+    return guarded([&] {
+        if ((!records && n) || !out) throw Error(GS_ERR_INVALID, "null argument");
+        select_device(device);
+        auto s = std::make_unique<gs_scene>();
+        s->device = device;
+        activate_and_upload(s.get(), records, n);
+        *out = s.release();
+    });
+}
+
+int gs_scene_from_vertices(const float* vertices, uint64_t n, int device, gs_scene** out) {
+    return guarded([&] {
+        if ((!vertices && n) || !out) throw Error(GS_ERR_INVALID, "null argument");
+        select_device(device);
+        auto s = std::make_unique<gs_scene>();
+        s->device = device;
+        upload_vertices(s.get(), vertices, n);
+        *out = s.release();
+    });
+}
+
+uint64_t gs_scene_blob_floats(uint64_t n) { return static_cast<uint64_t>(gs::P_COUNT) * n; }
+
+int gs_scene_from_device_blob(float* d_blob, uint64_t n, int device, gs_scene** out) {
+    return guarded([&] {
+        if ((!d_blob && n) || !out) throw Error(GS_ERR_INVALID, "null argument");
+        if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
+        select_device(device);
+        auto s = std::make_unique<gs_scene>();
+        s->device = device;
+        s->n = n;
+        s->blob = d_blob;
+        s->finish_load();
+        *out = s.release();
+    });
+}
+
+int gs_scene_blob(const gs_scene* s, float** d_blob, uint64_t* floats) {
+    return guarded([&] {
+        if (!s || !d_blob || !floats) throw Error(GS_ERR_INVALID, "null argument");
+        *d_blob = s->blob;
+        *floats = gs_scene_blob_floats(s->n);
+    });
+}
+
+uint64_t gs_scene_num_vertices(const gs_scene* s) { return s ? s->n : 0; }
+
+int gs_scene_download_vertices(const gs_scene* s, float* vertices) {
+    return guarded([&] {
+        if (!s || (!vertices && s->n)) throw Error(GS_ERR_INVALID, "null argument");
+        HIP_CHECK(hipSetDevice(s->device));
+        const uint64_t n = s->n;
+        std::vector<float> planes(static_cast<size_t>(gs::P_COUNT) * n);
+        if (n) HIP_CHECK(hipMemcpy(planes.data(), s->blob, planes.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) {
+            float* v = vertices + i * gs::host::kVertexFloats;
+            for (int k = 0; k < 3; ++k) v[k] = planes[(gs::P_POS + k) * n + i];
+            v[3] = 1.0f;
+            for (int k = 0; k < 3; ++k) v[4 + k] = planes[(gs::P_SCALE + k) * n + i];
+            v[7] = planes[static_cast<size_t>(gs::P_OPACITY) * n + i];
+            for (int k = 0; k < 4; ++k) v[8 + k] = planes[(gs::P_ROT + k) * n + i];
+            for (int k = 0; k < 48; ++k) v[12 + k] = planes[(gs::P_SH + k) * n + i];
+        }
+    });
+}
+
+int gs_scene_download_cov3d(const gs_scene* s, float* cov3d) {
+    return guarded([&] {
+        if (!s || (!cov3d && s->n)) throw Error(GS_ERR_INVALID, "null argument");
+        HIP_CHECK(hipSetDevice(s->device));
+        const uint64_t n = s->n;
+        std::vector<float> planes(6 * static_cast<size_t>(n));
+        if (n) HIP_CHECK(hipMemcpy(planes.data(), s->cov3d.p, planes.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i)
+            for (int k = 0; k < 6; ++k) cov3d[i * 6 + k] = planes[k * n + i];
+    });
+}
+
+void gs_scene_destroy(gs_scene* s) { delete s; }
+
+int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
+    return guarded([&] {
+        if (!scene || !out) throw Error(GS_ERR_INVALID, "null argument");
+        auto r = std::make_unique<gs_renderer>();
+        r->scene = scene;
+        r->init();
+        *out = r.release();
+    });
+}
+
+void gs_renderer_destroy(gs_renderer* r) {
+    if (r && r->stream) (void)hipStreamSynchronize(r->stream);
+    delete r;
+}
+
+int gs_camera_uniforms(const gs_camera* cam, uint32_t width, uint32_t height, gs_uniforms* out) {
+    return guarded([&] {
+        if (!cam || !out) throw Error(GS_ERR_INVALID, "null argument");
+        if (width == 0 || height == 0) throw Error(GS_ERR_INVALID, "empty framebuffer");
+        gs::host::camera_uniforms(*cam, width, height, out);
+    });
+}
+
+int gs_render(gs_renderer* r, const gs_uniforms* u, float* d_rgba, uint8_t* d_bgra) {
+    return guarded([&] {
+        if (!r || !u) throw Error(GS_ERR_INVALID, "null argument");
+        if (u->width == 0 || u->height == 0) throw Error(GS_ERR_INVALID, "empty framebuffer");
+        r->finish();  // one frame in flight; resolves a pending overflow first
+        r->enqueue(*u, d_rgba, d_bgra);
+    });
+}
+
+int gs_render_host(gs_renderer* r, const gs_uniforms* u, float* h_rgba, uint8_t* h_bgra) {
+    return guarded([&] {
+        if (!r || !u) throw Error(GS_ERR_INVALID, "null argument");
+        if (u->width == 0 || u->height == 0) throw Error(GS_ERR_INVALID, "empty framebuffer");
+        HIP_CHECK(hipSetDevice(r->scene->device));
+        const size_t px = static_cast<size_t>(u->width) * u->height;
+        DevBuf<float> d_rgba;
+        DevBuf<uint8_t> d_bgra;
+        if (h_rgba) d_rgba.alloc(px * 4);
+        if (h_bgra) d_bgra.alloc(px * 4);
+        r->finish();
+        r->enqueue(*u, h_rgba ? d_rgba.p : nullptr, h_bgra ? d_bgra.p : nullptr);
+        r->finish();
+        if (h_rgba) HIP_CHECK(hipMemcpy(h_rgba, d_rgba.p, px * 4 * sizeof(float), hipMemcpyDeviceToHost));
+        if (h_bgra) HIP_CHECK(hipMemcpy(h_bgra, d_bgra.p, px * 4, hipMemcpyDeviceToHost));
+        r->last_rgba = nullptr;  // temporaries die here
+        r->last_bgra = nullptr;
+    });
+}
+
+int gs_synchronize(gs_renderer* r) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "null argument");
+        r->finish();
+    });
+}
+
+int gs_set_timing(gs_renderer* r, int enabled) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "null argument");
+        r->finish();
+        r->timing = enabled != 0;
+    });
+}
+
+int gs_set_debug_taps(gs_renderer* r, int enabled) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "null argument");
+        r->finish();
+        r->keep_taps = enabled != 0;
+    });
+}
+
+int gs_get_stats(gs_renderer* r, gs_frame_stats* out) {
+    return guarded([&] {
+        if (!r || !out) throw Error(GS_ERR_INVALID, "null argument");
+        r->finish();
+        *out = gs_frame_stats{};
+        out->num_gaussians = r->scene->n;
+        out->instance_capacity = r->capacity;
+        out->retries = r->retries;
+        if (!r->have_frame) return;
+        out->num_visible = r->h_counters->visible;
+        out->num_instances = r->h_counters->instances;
+        auto span = [&](int a, int b) {
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, r->ev[a], r->ev[b]));
+            return ms;
+        };
+        out->ms_total = span(0, 7);
+        if (r->timing) {
+            out->ms_preprocess = span(0, 1);
+            out->ms_sort = span(1, 2) + span(4, 5);
+            out->ms_prefix_sum = span(2, 3);
+            out->ms_preprocess_sort = span(3, 4);
+            out->ms_tile_boundary = span(5, 6);
+            out->ms_render = span(6, 7);
+        }
+    });
+}
+
+int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
+    return guarded([&] {
+        if (!r || !dst) throw Error(GS_ERR_INVALID, "null argument");
+        r->finish();
+        if (!r->have_frame) throw Error(GS_ERR_INVALID, "no frame rendered yet");
+        const uint64_t n = r->scene->n, v = r->h_counters->visible;
+        const uint64_t d = std::min<uint64_t>(r->h_counters->instances, r->capacity);
+        const void* src = nullptr;
+        uint64_t size = 0;
+        switch (stage) {
+            case GS_STAGE_TILES: src = r->tiles.p; size = n * 4; break;
+            case GS_STAGE_DEPTH: src = r->depth.p; size = n * 4; break;
+            case GS_STAGE_RADIUS: src = r->radius.p; size = n * 4; break;
+            case GS_STAGE_AABB: src = r->aabb.p; size = n * 8; break;
+            case GS_STAGE_CONIC_OPACITY: src = r->conic_op.p; size = n * 16; break;
+            case GS_STAGE_UV_RG: src = r->uv_rg.p; size = n * 16; break;
+            case GS_STAGE_B: src = r->bch.p; size = n * 4; break;
+            case GS_STAGE_DEPTH_ORDER: src = r->depth_order; size = v * 4; break;
+            case GS_STAGE_OFFSETS: src = r->offsets.p; size = v * 4; break;
+            case GS_STAGE_INSTANCE_TILE:
+            case GS_STAGE_INSTANCE_GID:
+                if (!r->keep_taps) throw Error(GS_ERR_INVALID, "enable gs_set_debug_taps before rendering to read pre-sort instances");
+                src = stage == GS_STAGE_INSTANCE_TILE ? r->inst_tile : r->inst_gid;
+                size = d * 4;
+                break;
+            case GS_STAGE_SORTED_TILE: src = r->sorted_tile; size = d * 4; break;
+            case GS_STAGE_SORTED_GID: src = r->sorted_gid; size = d * 4; break;
+            case GS_STAGE_RANGES: src = r->ranges.p; size = r->num_tiles * 8; break;
+            default: throw Error(GS_ERR_INVALID, "unknown stage");
+        }
+        if (bytes < size) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
+        if (size) HIP_CHECK(hipMemcpy(dst, src, size, hipMemcpyDeviceToHost));
+    });
+}
+
+void* gs_renderer_stream(gs_renderer* r) { return r ? r->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// gs_kernels.h -- launch wrappers of the gfx950 kernels (gs_kernels.hip).
+// Host-side declarations only; everything takes raw device pointers + a stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gs3d_hip.h"
+
+namespace gs {
+
+constexpr int kTile = 16;             // TILE_WIDTH == TILE_HEIGHT, common.glsl:1-2
+constexpr int kSortTileKeys = 2048;   // keys per radix tile (256 threads x 8)
+constexpr int kSortMaxBlocks = 1024;  // fixed sort grid (data-dependent sizes stay on the device)
+constexpr int kScanBlocks = 512;      // fixed scan grid
+
+// Packed SoA scene blob: plane p of Gaussian i is blob[p*n + i].
+enum ScenePlane { P_POS = 0, P_SCALE = 3, P_ROT = 6, P_OPACITY = 10, P_SH = 11, P_COUNT = 59 };
+
+struct SceneView {
+    const float* blob;   // 59 planes
+    const float* cov3d;  // 6 planes
+    uint32_t n;
+};
+
+// Per-frame buffers indexed by Gaussian id.
+struct AttrView {
+    uint32_t* tiles;     // tiles_overlap (0 = culled)
+    float* depth;
+    float* radius;
+    ushort4* aabb;
+    float4* conic_op;    // c00 c01 c11 opacity
+    float4* uv_rg;       // u v r g
+    float* b;
+};
+
+// Device-resident frame counters.
+struct Counters {
+    uint32_t visible;    // V
+    uint32_t instances;  // D (may exceed capacity: then `overflow` is set and nothing past capacity is written)
+    uint32_t overflow;
+    uint32_t pad;
+};
+
+void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s);
+void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, hipStream_t s);
+
+// Stable LSD radix pass on (u32 key, u32 value) pairs, 8-bit digit at `shift`.
+//   first != 0: the input is (key = bits(depth[i]), value = i) for every i < n_static with tiles[i] != 0
+//               (compaction folded into the first pass); the element count is written to *n_out.
+//   first == 0: the element count is read from *n_in (device memory).
+// scratch: block histograms, 256 * (blocks + 1) uint32.
+struct RadixPass {
+    const uint32_t* keys_in;
+    const uint32_t* vals_in;
+    uint32_t* keys_out;
+    uint32_t* vals_out;
+    const uint32_t* n_in;     // device count (first == 0)
+    uint32_t n_static;        // N (first != 0) or the capacity bound used to size the grid
+    const uint32_t* tiles;    // first != 0
+    uint32_t* n_out;          // first != 0
+    uint32_t* block_hist;     // [256][blocks]
+    uint32_t* digit_total;    // [256]
+    int shift;
+    int bits;                 // significant bits in this digit (<= 8)
+    int blocks;
+    int first;
+    const uint32_t* gather_tiles;  // last depth pass: also emit tiles[value] in sorted order ...
+    uint32_t* tiles_sorted;        // ... here (may be null)
+};
+void launch_radix_pass(const RadixPass& p, hipStream_t s);
+
+// Exclusive scan of cnt[0..*n) -> off, total -> *total_out (3 kernels, fixed grid).
+void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n, uint32_t n_bound,
+                           uint32_t* partial, uint32_t* total_out, hipStream_t s);
+
+// preprocess_sort.comp counterpart, in depth order: for j < *n_visible, g = order[j], writes
+// tile ids (x outer, y inner) and g at off[j]...  Sets counters->overflow when D > capacity.
+void launch_duplicate(const uint32_t* order, const uint32_t* off, const uint32_t* tiles_sorted,
+                      const ushort4* aabb, const uint32_t* n_visible, uint32_t n_bound, uint32_t tiles_x,
+                      uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,
+                      hipStream_t s);
+
+// tile_boundary.comp counterpart (ranges must be zero-filled before).
+void launch_tile_ranges(const uint32_t* sorted_tile, const uint32_t* n, uint32_t capacity, uint32_t* ranges,
+                        hipStream_t s);
+
+// render.comp counterpart.
+void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const AttrView& av, uint32_t width,
+                  uint32_t height, float* rgba, uint8_t* bgra, hipStream_t s);
+
+}  // namespace gs

@@ -1,0 +1,811 @@
+// gs_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the splat pipeline.
+//
+// Build with -ffp-contract=off: the floating-point contract of this path is "IEEE binary32,
+// one rounding per operation, in the order the reference shader writes it" (DESIGN.md §3), so
+// that pixel output does not depend on a compiler's fusion choices.  Fused multiply-adds
+// appear only where written explicitly (gs_exp).
+//
+// Reference shaders restated (paths relative to /root/reference/src/shaders):
+//   k_cov3d        precomp_cov3d.comp:25-47, common.glsl:51-75
+//   k_preprocess   preprocess.comp:34-183
+//   k_radix_*      sort/hist.comp + sort/sort.comp (result: stable ascending order)
+//   k_scan_*       prefix_sum.comp:32-59 (result: prefix sums)
+//   k_duplicate    preprocess_sort.comp:31-61
+//   k_tile_ranges  tile_boundary.comp:22-50
+//   k_blend        render.comp:30-99
+#include "gs_kernels.h"
+
+namespace gs {
+
+#define WAVE 64
+#define BLOCK 256
+
+// ---------------------------------------------------------------------------------------
+// small column-major 3x3 helpers (GLSL conventions: c[col][row])
+// ---------------------------------------------------------------------------------------
+struct M3 {
+    float c[3][3];
+};
+
+// GLSL mat3 * mat3: (A*B)[c][r] = sum_k A[k][r] * B[c][k], k ascending, no fusion.
+__device__ __forceinline__ M3 m3_mul(const M3& a, const M3& b) {
+    M3 o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float s = a.c[0][r] * b.c[c][0];
+            s = s + a.c[1][r] * b.c[c][1];
+            s = s + a.c[2][r] * b.c[c][2];
+            o.c[c][r] = s;
+        }
+    return o;
+}
+__device__ __forceinline__ M3 m3_transpose(const M3& a) {
+    M3 o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o.c[c][r] = a.c[r][c];
+    return o;
+}
+
+// float -> int, toward zero, saturating; after the clamp to [0, tiles] the result equals the
+// reference's int() for every in-range input (out-of-range int() is undefined in GLSL).
+__device__ __forceinline__ int f2i_sat(float v) {
+    v = fminf(fmaxf(v, -2147483648.0f), 2147483520.0f);
+    return (int)v;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// exp() of render.comp:77 -- the pipeline's definition: 2^(x log2 e) with a
+// round-to-nearest integer split done in the mantissa (magic-number add), a degree-6 minimax
+// polynomial in explicit FMAs and an exponent-field add.  < 2 ULP on [-6, 0]; inside GLSL's
+// 3+2|x| ULP allowance everywhere.  x must be <= 88; values below -87 are clamped.
+__device__ __forceinline__ float gs_exp(float x) {
+    const float L2E = 1.44269502162933349609375f;
+    const float MAGIC = 12582912.0f;
+    x = fmaxf(x, -87.0f);
+    float tm = __builtin_fmaf(x, L2E, MAGIC);
+    float n = tm - MAGIC;
+    float f = __builtin_fmaf(x, L2E, -n);
+    float p = 0x1.41d332p-13f;
+    p = __builtin_fmaf(p, f, 0x1.5f456ap-10f);
+    p = __builtin_fmaf(p, f, 0x1.3b2dbcp-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6aed4p-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebfbdap-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e430p-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(tm) << 23));
+}
+
+// ---------------------------------------------------------------------------------------
+// cov3D precompute (load time).  precomp_cov3d.comp:25-47.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ M3 rotation_from_quaternion(float qw, float qx, float qy, float qz) {
+    float qx2 = qx * qx, qy2 = qy * qy, qz2 = qz * qz;
+    M3 m;
+    m.c[0][0] = 1 - 2 * qy2 - 2 * qz2;
+    m.c[0][1] = 2 * qx * qy - 2 * qz * qw;
+    m.c[0][2] = 2 * qx * qz + 2 * qy * qw;
+    m.c[1][0] = 2 * qx * qy + 2 * qz * qw;
+    m.c[1][1] = 1 - 2 * qx2 - 2 * qz2;
+    m.c[1][2] = 2 * qy * qz - 2 * qx * qw;
+    m.c[2][0] = 2 * qx * qz - 2 * qy * qw;
+    m.c[2][1] = 2 * qy * qz + 2 * qx * qw;
+    m.c[2][2] = 1 - 2 * qx2 - 2 * qy2;
+    return m;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cov3d(const float* __restrict__ blob, float* __restrict__ cov3d,
+                                                 uint32_t n) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = n;
+    const float scale_factor = 1.0f;  // GSScene.cpp:176
+    M3 S = {};
+    S.c[0][0] = blob[(P_SCALE + 0) * N + i] * scale_factor;
+    S.c[1][1] = blob[(P_SCALE + 1) * N + i] * scale_factor;
+    S.c[2][2] = blob[(P_SCALE + 2) * N + i] * scale_factor;
+    M3 R = rotation_from_quaternion(blob[(P_ROT + 0) * N + i], blob[(P_ROT + 1) * N + i],
+                                    blob[(P_ROT + 2) * N + i], blob[(P_ROT + 3) * N + i]);
+    M3 M = m3_mul(S, R);
+    M3 C = m3_mul(m3_transpose(M), M);
+    cov3d[0 * N + i] = C.c[0][0];
+    cov3d[1 * N + i] = C.c[0][1];
+    cov3d[2 * N + i] = C.c[0][2];
+    cov3d[3 * N + i] = C.c[1][1];
+    cov3d[4 * N + i] = C.c[1][2];
+    cov3d[5 * N + i] = C.c[2][2];
+}
+
+void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_cov3d, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob, cov3d, n);
+}
+
+// ---------------------------------------------------------------------------------------
+// preprocess.  One thread per Gaussian, SoA plane loads (coalesced 256 B per wave and plane);
+// the 48 SH planes are read only by lanes that survive every cull.
+// ---------------------------------------------------------------------------------------
+constexpr float SH_C0 = 0.28209479177387814f;  // common.glsl:16-33
+constexpr float SH_C1 = 0.4886025119029199f;
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * (float)S - 1.0f) * 0.5f; }
+
+struct PreUniforms {
+    gs_uniforms u;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms pu, AttrView av) {
+    const gs_uniforms& u = pu.u;
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= sv.n) return;
+    const size_t N = sv.n;
+    const float* __restrict__ blob = sv.blob;
+
+    const int tile_w = (int)((u.width + kTile - 1) / kTile);
+    const int tile_h = (int)((u.height + kTile - 1) / kTile);
+
+    const float px = blob[(P_POS + 0) * N + i];
+    const float py = blob[(P_POS + 1) * N + i];
+    const float pz = blob[(P_POS + 2) * N + i];
+
+    uint32_t num_tiles = 0;
+    do {
+        // preprocess.comp:130-135 (position.w == 1)
+        float p_hom[4], p_view[3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = u.proj_mat[0 * 4 + r] * px;
+            s = s + u.proj_mat[1 * 4 + r] * py;
+            s = s + u.proj_mat[2 * 4 + r] * pz;
+            s = s + u.proj_mat[3 * 4 + r] * 1.0f;
+            p_hom[r] = s;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float s = u.view_mat[0 * 4 + r] * px;
+            s = s + u.view_mat[1 * 4 + r] * py;
+            s = s + u.view_mat[2 * 4 + r] * pz;
+            s = s + u.view_mat[3 * 4 + r] * 1.0f;
+            p_view[r] = s;
+        }
+        const float p_w = 1.0f / p_hom[3];
+        const float ndc_x = p_hom[0] * p_w, ndc_y = p_hom[1] * p_w;
+        if (p_view[2] <= 0.2f) break;
+
+        // preprocess.comp:34-52 get_projection_jacobian_approx
+        float tx = p_view[0], ty = p_view[1];
+        const float tz = p_view[2];
+        const float limx = 1.3f * u.tan_fovx;
+        const float limy = 1.3f * u.tan_fovy;
+        const float txtz = tx / tz;
+        const float tytz = ty / tz;
+        tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const float focal_x = (float)u.width / (2 * u.tan_fovx);
+        const float focal_y = (float)u.height / (2 * u.tan_fovy);
+        M3 J;
+        J.c[0][0] = focal_x / tz;
+        J.c[0][1] = 0;
+        J.c[0][2] = -(focal_x * tx) / (tz * tz);
+        J.c[1][0] = 0;
+        J.c[1][1] = focal_y / tz;
+        J.c[1][2] = -(focal_y * ty) / (tz * tz);
+        J.c[2][0] = 0;
+        J.c[2][1] = 0;
+        J.c[2][2] = 0;
+
+        // preprocess.comp:54-66 compute_cov2d
+        M3 W;  // transpose(mat3(view_mat))
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) W.c[c][r] = u.view_mat[r * 4 + c];
+        const float* __restrict__ cv = sv.cov3d;
+        const float s0 = cv[0 * N + i], s1 = cv[1 * N + i], s2 = cv[2 * N + i];
+        const float s3 = cv[3 * N + i], s4 = cv[4 * N + i], s5 = cv[5 * N + i];
+        M3 Sigma;
+        Sigma.c[0][0] = s0;
+        Sigma.c[0][1] = s1;
+        Sigma.c[0][2] = s2;
+        Sigma.c[1][0] = s1;
+        Sigma.c[1][1] = s3;
+        Sigma.c[1][2] = s4;
+        Sigma.c[2][0] = s2;
+        Sigma.c[2][1] = s4;
+        Sigma.c[2][2] = s5;
+        M3 T = m3_mul(W, J);
+        M3 cov = m3_mul(m3_mul(m3_transpose(T), Sigma), T);
+        const float m00 = cov.c[0][0] + 0.3f;
+        const float m11 = cov.c[1][1] + 0.3f;
+        const float m01 = cov.c[0][1], m10 = cov.c[1][0];
+
+        const float det = m00 * m11 - m10 * m01;  // :140
+        if (det <= 0.0f) break;
+        const float inv_det = 1.0f / det;  // inverse(mat2) :144
+        const float c00 = m11 * inv_det;
+        const float c01 = -m01 * inv_det;
+        const float c11 = m00 * inv_det;
+
+        const float mid = 0.5f * (m00 + m11);  // :148-152
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda1 = mid + sq;
+        const float lambda2 = mid - sq;
+        const float lambda = fmaxf(lambda1, lambda2);
+        const float radii = ceilf(3.0f * sqrtf(lambda));
+
+        const float uvx = ndc2pix(ndc_x, (int)u.width);  // :158
+        const float uvy = ndc2pix(ndc_y, (int)u.height);
+
+        // :160-165 tile box
+        const int bx0 = clampi(f2i_sat((uvx - radii) / kTile), 0, tile_w);
+        const int by0 = clampi(f2i_sat((uvy - radii) / kTile), 0, tile_h);
+        const int bx1 = clampi(f2i_sat((uvx + radii + kTile - 1) / kTile), 0, tile_w);
+        const int by1 = clampi(f2i_sat((uvy + radii + kTile - 1) / kTile), 0, tile_h);
+        const uint32_t nt = (uint32_t)(bx1 - bx0) * (uint32_t)(by1 - by0);
+        if (nt == 0) break;
+
+        // :73-108 compute_sh (degree 3 always; only .x clamped)
+        const float opacity = blob[(size_t)P_OPACITY * N + i];
+        float dx = px - u.camera_position[0];
+        float dy = py - u.camera_position[1];
+        float dz = pz - u.camera_position[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx / len, y = dy / len, z = dz / len;
+        const float* __restrict__ sh = blob + (size_t)P_SH * N + i;
+        float rgb[3];
+        const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                    C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+        const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                    C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                    C3_6 = -0.5900435899266435f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#define S(j) sh[(size_t)((j) * 3 + k) * N]
+            float c = SH_C0 * S(0);
+            c -= SH_C1 * S(1) * y;
+            c += SH_C1 * S(2) * z;
+            c -= SH_C1 * S(3) * x;
+            c += C2_0 * S(4) * x * y;
+            c += C2_1 * S(5) * y * z;
+            c += C2_2 * S(6) * (2.0f * z * z - x * x - y * y);
+            c += C2_3 * S(7) * z * x;
+            c += C2_4 * S(8) * (x * x - y * y);
+            c += C3_0 * S(9) * (3.0f * x * x - y * y) * y;
+            c += C3_1 * S(10) * x * y * z;
+            c += C3_2 * S(11) * (4.0f * z * z - x * x - y * y) * y;
+            c += C3_3 * S(12) * z * (2.0f * z * z - 3.0f * x * x - 3.0f * y * y);
+            c += C3_4 * S(13) * x * (4.0f * z * z - x * x - y * y);
+            c += C3_5 * S(14) * (x * x - y * y) * z;
+            c += C3_6 * S(15) * x * (x * x - 3.0f * y * y);
+            c += 0.5f;
+#undef S
+            rgb[k] = c;
+        }
+        if (rgb[0] < 0.0f) rgb[0] = 0.0f;
+
+        num_tiles = nt;
+        av.depth[i] = p_view[2];
+        av.radius[i] = radii;
+        av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1,
+                                  (unsigned short)by1);
+        av.conic_op[i] = make_float4(c00, c01, c11, opacity);
+        av.uv_rg[i] = make_float4(uvx, uvy, rgb[0], rgb[1]);
+        av.b[i] = rgb[2];
+    } while (false);
+    av.tiles[i] = num_tiles;  // :128 / :176
+}
+
+void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, hipStream_t s) {
+    if (sv.n == 0) return;
+    PreUniforms pu;
+    pu.u = u;
+    hipLaunchKernelGGL(k_preprocess, dim3((sv.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, sv, pu, av);
+}
+
+// ---------------------------------------------------------------------------------------
+// block-wide exclusive scan of one uint per thread (256 threads = 4 waves).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Returns the exclusive prefix of v over the block; *total = block sum.  scratch: >= 8 uints of LDS.
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* scratch, uint32_t* total) {
+    constexpr int NW = THREADS / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    uint32_t incl = wave_incl_scan(v);
+    __syncthreads();  // scratch reuse
+    if (lane == WAVE - 1) scratch[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        uint32_t s = scratch[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Stable LSD radix pass (8-bit digit), fixed grid, element count resident on the device.
+// Element e of a 2048-key tile belongs to wave (e / 512), round ((e % 512) / 64), lane (e % 64):
+// every load is a coalesced 256-byte row and tile order == (wave, round, lane) order.
+// ---------------------------------------------------------------------------------------
+struct RadixArgs {
+    const uint32_t* keys_in;
+    const uint32_t* vals_in;
+    uint32_t* keys_out;
+    uint32_t* vals_out;
+    const uint32_t* n_in;
+    uint32_t n_static;
+    const uint32_t* tiles;
+    uint32_t* n_out;
+    uint32_t* block_hist;
+    uint32_t* digit_total;
+    const uint32_t* gather_tiles;
+    uint32_t* tiles_sorted;
+    int shift;
+    uint32_t mask;
+    int blocks;
+};
+
+template <bool FIRST>
+__device__ __forceinline__ uint32_t radix_count(const RadixArgs& a) {
+    if (FIRST) return a.n_static;
+    uint32_t n = *a.n_in;
+    return n < a.n_static ? n : a.n_static;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t e, uint32_t n, uint32_t& key,
+                                           uint32_t& val) {
+    if (e >= n) return false;
+    if (FIRST) {
+        if (a.tiles[e] == 0) return false;
+        key = a.keys_in[e];  // bits of depth[e]
+        val = e;
+    } else {
+        key = a.keys_in[e];
+        val = a.vals_in[e];
+    }
+    return true;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(BLOCK) void k_radix_hist(RadixArgs a) {
+    __shared__ uint32_t hist[256];
+    const uint32_t n = radix_count<FIRST>(a);
+    const uint32_t ntiles = (n + kSortTileKeys - 1) / kSortTileKeys;
+    const uint32_t t0 = (uint32_t)((uint64_t)blockIdx.x * ntiles / a.blocks);
+    const uint32_t t1 = (uint32_t)((uint64_t)(blockIdx.x + 1) * ntiles / a.blocks);
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t base = t * kSortTileKeys;
+#pragma unroll
+        for (int r = 0; r < kSortTileKeys / BLOCK; ++r) {
+            uint32_t key = 0, val = 0;
+            if (radix_load<FIRST>(a, base + r * BLOCK + threadIdx.x, n, key, val))
+                atomicAdd(&hist[(key >> a.shift) & a.mask], 1u);
+        }
+    }
+    __syncthreads();
+    a.block_hist[threadIdx.x * a.blocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// One block per digit: exclusive scan of that digit's row of block counts, row total out.
+__global__ __launch_bounds__(BLOCK) void k_radix_scan(uint32_t* block_hist, uint32_t* digit_total, int blocks) {
+    __shared__ uint32_t scratch[8];
+    uint32_t* row = block_hist + (size_t)blockIdx.x * blocks;
+    const int per = (blocks + BLOCK - 1) / BLOCK;  // <= 4
+    uint32_t v[4] = {0, 0, 0, 0};
+    uint32_t sum = 0;
+    for (int k = 0; k < per; ++k) {
+        int idx = threadIdx.x * per + k;
+        v[k] = idx < blocks ? row[idx] : 0;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t excl = block_excl_scan<BLOCK>(sum, scratch, &total);
+    for (int k = 0; k < per; ++k) {
+        int idx = threadIdx.x * per + k;
+        if (idx < blocks) row[idx] = excl;
+        excl += v[k];
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = total;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(BLOCK) void k_radix_scatter(RadixArgs a) {
+    __shared__ uint32_t s_keys[kSortTileKeys];
+    __shared__ uint32_t s_vals[kSortTileKeys];
+    __shared__ uint32_t s_wcnt[4][256];   // per-wave digit counters, then local positions
+    __shared__ uint32_t s_base[256];      // global write cursor of this block per digit
+    __shared__ uint32_t s_tcnt[256];      // digit counts of the current tile
+    __shared__ uint32_t s_texcl[256];     // exclusive scan of s_tcnt
+    __shared__ uint32_t scratch[8];
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const uint32_t n = radix_count<FIRST>(a);
+    const uint32_t ntiles = (n + kSortTileKeys - 1) / kSortTileKeys;
+    const uint32_t t0 = (uint32_t)((uint64_t)blockIdx.x * ntiles / a.blocks);
+    const uint32_t t1 = (uint32_t)((uint64_t)(blockIdx.x + 1) * ntiles / a.blocks);
+
+    {   // global digit base + this block's prefix inside the digit
+        uint32_t tot = a.digit_total[tid], all;
+        uint32_t excl = block_excl_scan<BLOCK>(tot, scratch, &all);
+        s_base[tid] = excl + a.block_hist[tid * a.blocks + blockIdx.x];
+        if (FIRST && blockIdx.x == 0 && tid == 0) *a.n_out = all;
+    }
+    __syncthreads();
+
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t base = t * kSortTileKeys + w * 512;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_wcnt[k][tid] = 0;
+        __syncthreads();
+
+        uint32_t key[8], val[8], rank[8];
+        bool ok[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            key[r] = 0;
+            val[r] = 0;
+            ok[r] = radix_load<FIRST>(a, base + r * WAVE + lane, n, key[r], val[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t d = (key[r] >> a.shift) & a.mask;
+            uint64_t m = __ballot(ok[r]);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool set = (d >> bit) & 1u;
+                const uint64_t b = __ballot(ok[r] && set);
+                m &= set ? b : ~b;
+            }
+            // m: lanes holding a valid key with my digit (meaningful where ok[r])
+            uint32_t old = 0;
+            const int leader = m ? (__ffsll((unsigned long long)m) - 1) : 0;
+            if (ok[r] && lane == leader) {
+                old = s_wcnt[w][d];
+                s_wcnt[w][d] = old + (uint32_t)__popcll(m);
+            }
+            old = __shfl(old, leader, WAVE);
+            rank[r] = old + (uint32_t)__popcll(m & lt_mask);
+        }
+        __syncthreads();
+        {   // per-digit: prefix over waves, tile count, exclusive scan over digits
+            const uint32_t c0 = s_wcnt[0][tid], c1 = s_wcnt[1][tid], c2 = s_wcnt[2][tid], c3 = s_wcnt[3][tid];
+            const uint32_t cnt = c0 + c1 + c2 + c3;
+            uint32_t all;
+            const uint32_t excl = block_excl_scan<BLOCK>(cnt, scratch, &all);
+            s_tcnt[tid] = cnt;
+            s_texcl[tid] = excl;
+            s_wcnt[0][tid] = excl;
+            s_wcnt[1][tid] = excl + c0;
+            s_wcnt[2][tid] = excl + c0 + c1;
+            s_wcnt[3][tid] = excl + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (ok[r]) {
+                const uint32_t d = (key[r] >> a.shift) & a.mask;
+                const uint32_t pos = s_wcnt[w][d] + rank[r];
+                s_keys[pos] = key[r];
+                s_vals[pos] = val[r];
+            }
+        }
+        __syncthreads();
+        const uint32_t tile_valid = s_texcl[255] + s_tcnt[255];
+#pragma unroll
+        for (int j = 0; j < kSortTileKeys / BLOCK; ++j) {
+            const uint32_t slot = j * BLOCK + tid;
+            if (slot < tile_valid) {
+                const uint32_t k2 = s_keys[slot], v2 = s_vals[slot];
+                const uint32_t d = (k2 >> a.shift) & a.mask;
+                const uint32_t dst = s_base[d] + (slot - s_texcl[d]);
+                a.keys_out[dst] = k2;
+                a.vals_out[dst] = v2;
+                if (a.tiles_sorted) a.tiles_sorted[dst] = a.gather_tiles[v2];
+            }
+        }
+        __syncthreads();
+        s_base[tid] += s_tcnt[tid];
+        // the barrier after zeroing s_wcnt at the top of the next tile orders this update
+    }
+}
+
+void launch_radix_pass(const RadixPass& p, hipStream_t s) {
+    RadixArgs a;
+    a.keys_in = p.keys_in;
+    a.vals_in = p.vals_in;
+    a.keys_out = p.keys_out;
+    a.vals_out = p.vals_out;
+    a.n_in = p.n_in;
+    a.n_static = p.n_static;
+    a.tiles = p.tiles;
+    a.n_out = p.n_out;
+    a.block_hist = p.block_hist;
+    a.digit_total = p.digit_total;
+    a.gather_tiles = p.gather_tiles;
+    a.tiles_sorted = p.tiles_sorted;
+    a.shift = p.shift;
+    a.mask = (1u << p.bits) - 1u;
+    a.blocks = p.blocks;
+    if (p.first) {
+        hipLaunchKernelGGL(k_radix_hist<true>, dim3(p.blocks), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(BLOCK), 0, s, p.block_hist, p.digit_total, p.blocks);
+        hipLaunchKernelGGL(k_radix_scatter<true>, dim3(p.blocks), dim3(BLOCK), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_radix_hist<false>, dim3(p.blocks), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(BLOCK), 0, s, p.block_hist, p.digit_total, p.blocks);
+        hipLaunchKernelGGL(k_radix_scatter<false>, dim3(p.blocks), dim3(BLOCK), 0, s, a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Exclusive scan (reduce / spine / downsweep), fixed grid of kScanBlocks.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
+    // contiguous, 1024-aligned slices
+    const uint32_t chunks = (n + 1023) / 1024;
+    lo = (uint32_t)((uint64_t)blockIdx.x * chunks / kScanBlocks) * 1024u;
+    hi = (uint32_t)((uint64_t)(blockIdx.x + 1) * chunks / kScanBlocks) * 1024u;
+    if (hi > n) hi = n;
+    if (lo > n) lo = n;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan_reduce(const uint32_t* __restrict__ cnt, const uint32_t* n_ptr,
+                                                       uint32_t n_bound, uint32_t* partial) {
+    __shared__ uint32_t scratch[8];
+    uint32_t n = *n_ptr;
+    if (n > n_bound) n = n_bound;
+    uint32_t lo, hi;
+    scan_range(n, lo, hi);
+    uint32_t sum = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += BLOCK) sum += cnt[i];
+    uint32_t total;
+    block_excl_scan<BLOCK>(sum, scratch, &total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanBlocks) void k_scan_spine(uint32_t* partial, uint32_t* total_out) {
+    __shared__ uint32_t scratch[8];
+    uint32_t v = partial[threadIdx.x], total;
+    uint32_t excl = block_excl_scan<kScanBlocks>(v, scratch, &total);
+    partial[threadIdx.x] = excl;
+    if (threadIdx.x == 0) *total_out = total;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan_down(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
+                                                     const uint32_t* n_ptr, uint32_t n_bound,
+                                                     const uint32_t* partial) {
+    __shared__ uint32_t scratch[8];
+    uint32_t n = *n_ptr;
+    if (n > n_bound) n = n_bound;
+    uint32_t lo, hi;
+    scan_range(n, lo, hi);
+    uint32_t running = partial[blockIdx.x];
+    for (uint32_t base = lo; base < hi; base += 1024) {
+        const uint32_t i0 = base + threadIdx.x * 4;  // base is 1024-aligned -> 16-byte aligned
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (i0 + 3 < hi) {
+            const uint4 q = *reinterpret_cast<const uint4*>(cnt + i0);
+            v[0] = q.x;
+            v[1] = q.y;
+            v[2] = q.z;
+            v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < hi) v[k] = cnt[i0 + k];
+        }
+        const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+        uint32_t total;
+        uint32_t excl = running + block_excl_scan<BLOCK>(sum, scratch, &total);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < hi) off[i0 + k] = excl;
+            excl += v[k];
+        }
+        running += total;
+    }
+}
+
+void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n, uint32_t n_bound,
+                           uint32_t* partial, uint32_t* total_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan_reduce, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, n, n_bound, partial);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kScanBlocks), 0, s, partial, total_out);
+    hipLaunchKernelGGL(k_scan_down, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, off, n, n_bound, partial);
+}
+
+// ---------------------------------------------------------------------------------------
+// duplicate: one lane per visible Gaussian (in depth order); boxes of >= 64 tiles are written
+// by the whole wave so that the widest splats do not serialise one lane.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_duplicate(const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ off,
+                                                     const uint32_t* __restrict__ tiles_sorted,
+                                                     const ushort4* __restrict__ aabb, const uint32_t* n_visible,
+                                                     uint32_t n_bound, uint32_t tiles_x, uint32_t capacity,
+                                                     uint32_t* __restrict__ inst_tile,
+                                                     uint32_t* __restrict__ inst_gid, Counters* counters) {
+    uint32_t n = *n_visible;
+    if (n > n_bound) n = n_bound;
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && counters->instances > capacity) counters->overflow = 1;
+    if (blockIdx.x * BLOCK >= n) return;
+
+    bool valid = j < n;
+    uint32_t g = 0, o = 0, cnt = 0;
+    ushort4 box = make_ushort4(0, 0, 0, 0);
+    if (valid) {
+        g = order[j];
+        o = off[j];
+        cnt = tiles_sorted[j];
+        box = aabb[g];
+        if ((uint64_t)o + cnt > capacity) valid = false;  // overflow: frame is re-run after growing
+    }
+    const bool big = valid && cnt >= WAVE;
+    uint64_t bm = __ballot(big);
+    while (bm) {
+        const int src = __ffsll((unsigned long long)bm) - 1;
+        bm &= bm - 1;
+        const uint32_t x0 = __shfl((uint32_t)box.x, src, WAVE), y0 = __shfl((uint32_t)box.y, src, WAVE);
+        const uint32_t y1 = __shfl((uint32_t)box.w, src, WAVE);
+        const uint32_t c = __shfl(cnt, src, WAVE), ob = __shfl(o, src, WAVE), gs_ = __shfl(g, src, WAVE);
+        const uint32_t h = y1 - y0;
+        for (uint32_t k = lane; k < c; k += WAVE) {
+            const uint32_t xi = k / h, yi = k - xi * h;  // x outer, y inner (preprocess_sort.comp:47-48)
+            inst_tile[ob + k] = (x0 + xi) + (y0 + yi) * tiles_x;
+            inst_gid[ob + k] = gs_;
+        }
+    }
+    if (valid && !big) {
+        uint32_t ind = o;
+        for (uint32_t x = box.x; x < box.z; ++x)
+            for (uint32_t y = box.y; y < box.w; ++y) {
+                inst_tile[ind] = x + y * tiles_x;
+                inst_gid[ind] = g;
+                ++ind;
+            }
+    }
+}
+
+void launch_duplicate(const uint32_t* order, const uint32_t* off, const uint32_t* tiles_sorted,
+                      const ushort4* aabb, const uint32_t* n_visible, uint32_t n_bound, uint32_t tiles_x,
+                      uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,
+                      hipStream_t s) {
+    if (n_bound == 0) return;
+    hipLaunchKernelGGL(k_duplicate, dim3((n_bound + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, order, off,
+                       tiles_sorted, aabb, n_visible, n_bound, tiles_x, capacity, inst_tile, inst_gid, counters);
+}
+
+// ---------------------------------------------------------------------------------------
+// tile ranges.  tile_boundary.comp:22-50 (ranges zero-filled by the caller, Renderer.cpp:633).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_tile_ranges(const uint32_t* __restrict__ sorted_tile,
+                                                       const uint32_t* n_ptr, uint32_t capacity,
+                                                       uint32_t* __restrict__ ranges) {
+    uint32_t n = *n_ptr;
+    if (n > capacity) n = capacity;
+    for (uint32_t index = blockIdx.x * BLOCK + threadIdx.x; index < n; index += gridDim.x * BLOCK) {
+        const uint32_t key = sorted_tile[index];
+        if (index == 0) {
+            ranges[key * 2] = index;
+        } else {
+            const uint32_t prev = sorted_tile[index - 1];
+            if (key != prev) {
+                ranges[key * 2] = index;
+                ranges[prev * 2 + 1] = index;
+            }
+        }
+        if (index == n - 1) ranges[key * 2 + 1] = n;
+    }
+}
+
+void launch_tile_ranges(const uint32_t* sorted_tile, const uint32_t* n, uint32_t capacity, uint32_t* ranges,
+                        hipStream_t s) {
+    if (capacity == 0) return;
+    uint32_t blocks = (capacity + BLOCK - 1) / BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_tile_ranges, dim3(blocks), dim3(BLOCK), 0, s, sorted_tile, n, capacity, ranges);
+}
+
+// ---------------------------------------------------------------------------------------
+// blend.  One 256-thread workgroup per 16x16 tile; each wave owns an 8x8 pixel quadrant.
+// The tile's list is fetched in batches of 256 entries: thread t gathers entry t's record
+// (9 floats) once into LDS, then all pixels walk the batch with broadcast LDS reads.
+// render.comp:61-98 semantics, operation order as written there.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ ranges,
+                                                 const uint32_t* __restrict__ sorted_gid,
+                                                 const float4* __restrict__ conic_op,
+                                                 const float4* __restrict__ uv_rg, const float* __restrict__ bch,
+                                                 uint32_t width, uint32_t height, uint32_t tiles_x,
+                                                 float4* __restrict__ rgba, uchar4* __restrict__ bgra) {
+    __shared__ float4 s_co[BLOCK];
+    __shared__ float4 s_uv[BLOCK];
+    __shared__ float s_b[BLOCK];
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const uint32_t px = blockIdx.x * kTile + (w & 1) * 8 + (lane & 7);
+    const uint32_t py = blockIdx.y * kTile + (w >> 1) * 8 + (lane >> 3);
+    const bool inside = px < width && py < height;  // render.comp:36-39
+    const float fx = (float)px, fy = (float)py;
+
+    const uint2 range = ranges[blockIdx.x + blockIdx.y * tiles_x];
+    float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    bool done = !inside;
+
+    for (uint32_t base = range.x; base < range.y; base += BLOCK) {
+        if (__syncthreads_and(done)) break;  // whole tile saturated; also fences LDS reuse
+        const uint32_t cnt = min((uint32_t)BLOCK, range.y - base);
+        if ((uint32_t)tid < cnt) {
+            const uint32_t g = sorted_gid[base + tid];
+            s_co[tid] = conic_op[g];
+            s_uv[tid] = uv_rg[g];
+            s_b[tid] = bch[g];
+        }
+        __syncthreads();
+        if (!done) {
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4 co = s_co[k];
+                const float4 uv = s_uv[k];
+                const float dx = uv.x - fx;
+                const float dy = uv.y - fy;
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;  // :66
+                if (power > 0.0f) continue;
+                const float alpha = fminf(0.99f, co.w * gs_exp(power));  // :77
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T * (1 - alpha);
+                if (test_T < 0.0001f) {  // :82-85
+                    done = true;
+                    break;
+                }
+                c0 += uv.z * alpha * T;  // :87
+                c1 += uv.w * alpha * T;
+                c2 += s_b[k] * alpha * T;
+                T = test_T;
+            }
+        }
+    }
+    if (inside) {
+        const size_t p = (size_t)py * width + px;
+        if (rgba) rgba[p] = make_float4(c0, c1, c2, 1.0f);  // :98
+        if (bgra) {
+            // imageStore to B8G8R8A8_UNORM: clamp to [0,1], round to nearest
+            const float r = fminf(fmaxf(c0, 0.0f), 1.0f), g = fminf(fmaxf(c1, 0.0f), 1.0f),
+                        b = fminf(fmaxf(c2, 0.0f), 1.0f);
+            bgra[p] = make_uchar4((unsigned char)(int)__builtin_rintf(b * 255.0f),
+                                  (unsigned char)(int)__builtin_rintf(g * 255.0f),
+                                  (unsigned char)(int)__builtin_rintf(r * 255.0f), 255);
+        }
+    }
+}
+
+void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const AttrView& av, uint32_t width,
+                  uint32_t height, float* rgba, uint8_t* bgra, hipStream_t s) {
+    if (width == 0 || height == 0) return;
+    const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_blend, dim3(tx, ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
+                       sorted_gid, av.conic_op, av.uv_rg, av.b, width, height, tx,
+                       reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra));
+}
+
+}  // namespace gs

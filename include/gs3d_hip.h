@@ -1,0 +1,164 @@
+/*
+ * gs3d_hip.h -- C ABI of libgs3d_hip.so, the MI355X (gfx950) splat rasterizer.
+ *
+ * This is the drop-in boundary for the per-frame hot path of shg8/3DGS.cpp
+ * (preprocess -> scan -> duplicate -> sort -> tile ranges -> alpha blend).
+ * Plain pointers and sizes only; no C++/torch types.  Each entry point names
+ * the reference interface it replaces (paths relative to /root/reference).
+ * The reference-API C++ mirror (VulkanSplatting / Renderer / GSScene) in
+ * include/3dgs/ and 3dgs.cpp_amd/csrc/host/ is a thin layer over these calls.
+ *
+ * All functions return 0 on success and a negative gs_status on failure;
+ * gs_last_error() returns the message for the calling thread (the reference
+ * throws std::runtime_error with the same text, e.g. GSScene.h:29).
+ * Handles are not thread-safe; one HIP stream per renderer; one frame in
+ * flight per renderer (VulkanContext.h:6 FRAMES_IN_FLIGHT 1).
+ */
+#ifndef GS3D_HIP_H
+#define GS3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gs_scene gs_scene;       /* replaces class GSScene,  src/GSScene.h:23-65   */
+typedef struct gs_renderer gs_renderer; /* replaces class Renderer, src/Renderer.h:19-168 */
+
+enum gs_status {
+    GS_OK = 0,
+    GS_ERR_INVALID = -1,   /* bad argument */
+    GS_ERR_IO = -2,        /* file missing / malformed PLY (GSScene.h:29, GSScene.cpp:101,147) */
+    GS_ERR_DEVICE = -3,    /* HIP error, or no gfx950 device: there is NO CPU fallback */
+    GS_ERR_NOMEM = -4,
+    GS_ERR_OVERFLOW = -5   /* instance buffers could not be grown (Renderer.cpp:541-563) */
+};
+
+/* Renderer::Camera, src/Renderer.h:40-50 (defaults :79-85). */
+typedef struct {
+    float position[3];
+    float rotation[4]; /* quaternion w, x, y, z */
+    float fov;         /* degrees, horizontal */
+    float near_plane;
+    float far_plane;
+} gs_camera;
+
+/* Renderer::UniformBuffer, src/Renderer.h:21-29; std140, 160 bytes, column-major. */
+typedef struct {
+    float camera_position[4];
+    float proj_mat[16];
+    float view_mat[16];
+    uint32_t width;
+    uint32_t height;
+    float tan_fovx;
+    float tan_fovy;
+} gs_uniforms;
+
+/* Timestamps of Renderer::retrieveTimestamps (Renderer.cpp:85-100): the six span
+ * names registered at Renderer.cpp:484-526,580-699, plus the "instances" metric
+ * (Renderer.cpp:540). */
+typedef struct {
+    uint64_t num_gaussians; /* N */
+    uint64_t num_visible;   /* V = #Gaussians with tiles_overlap != 0 */
+    uint64_t num_instances; /* D = "instances" */
+    uint64_t instance_capacity;
+    float ms_preprocess;
+    float ms_prefix_sum;
+    float ms_preprocess_sort;
+    float ms_sort;
+    float ms_tile_boundary;
+    float ms_render;
+    float ms_total;
+    uint32_t retries; /* frames re-run after growing the instance buffers */
+} gs_frame_stats;
+
+/* Stage taps for parity tests (the role of Buffer::download / assertEquals,
+ * src/vulkan/Buffer.cpp:176-226).  Layouts are documented in DESIGN.md. */
+enum gs_stage {
+    GS_STAGE_TILES = 0,          /* uint32[N]  tiles_overlap                                  */
+    GS_STAGE_DEPTH = 1,          /* float[N]   view-space depth (valid where tiles != 0)      */
+    GS_STAGE_RADIUS = 2,         /* float[N]                                                  */
+    GS_STAGE_AABB = 3,           /* uint16[4N] x0 y0 x1 y1                                    */
+    GS_STAGE_CONIC_OPACITY = 4,  /* float[4N]                                                 */
+    GS_STAGE_UV_RG = 5,          /* float[4N]  u v r g                                        */
+    GS_STAGE_B = 6,              /* float[N]   b                                              */
+    GS_STAGE_DEPTH_ORDER = 7,    /* uint32[V]  visible Gaussian ids, ascending (depth, id)    */
+    GS_STAGE_OFFSETS = 8,        /* uint32[V]  exclusive scan of tiles_overlap in that order  */
+    GS_STAGE_INSTANCE_TILE = 9,  /* uint32[D]  tile id per instance before the tile sort      */
+    GS_STAGE_INSTANCE_GID = 10,  /* uint32[D]  Gaussian id per instance before the tile sort  */
+    GS_STAGE_SORTED_TILE = 11,   /* uint32[D]  == sorted key >> 32 of the reference           */
+    GS_STAGE_SORTED_GID = 12,    /* uint32[D]  == sorted payload of the reference             */
+    GS_STAGE_RANGES = 13         /* uint32[2T] == tileBoundaryBuffer                          */
+};
+
+const char* gs_last_error(void);
+int gs_device_count(int* count);
+
+/* ---- scene: GSScene ------------------------------------------------------- */
+
+/* GSScene::GSScene(filename) + GSScene::load (GSScene.h:25-31, GSScene.cpp:26-68):
+ * parse the binary PLY, apply exp/sigmoid/normalize + SH reorder, upload as SoA,
+ * run the cov3D precompute (GSScene.cpp:157-184). */
+int gs_scene_load_ply(const char* path, int device, gs_scene** out);
+
+/* Same, from n PLY-domain records (62 floats each, GSScene.cpp:17-24) in host memory. */
+int gs_scene_from_records(const float* records, uint64_t n, int device, gs_scene** out);
+
+/* From n activated GSScene::Vertex structs (60 floats each, GSScene.h:41-46) in host
+ * memory: what vertexBuffer->uploadFrom(staging) transfers (GSScene.cpp:61). */
+int gs_scene_from_vertices(const float* vertices, uint64_t n, int device, gs_scene** out);
+
+/* Adopt a packed SoA blob already resident in HBM (gs_scene_blob_floats(n) floats:
+ * pos[3][n] scale[3][n] rot[4][n] opacity[n] sh[48][n]); the caller keeps it alive.
+ * This is the multi-GPU path: rank 0 builds the blob, RCCL broadcasts it, every rank
+ * adopts its copy.  No reference counterpart (the reference is single-GPU). */
+int gs_scene_from_device_blob(float* d_blob, uint64_t n, int device, gs_scene** out);
+uint64_t gs_scene_blob_floats(uint64_t n);
+int gs_scene_blob(const gs_scene* s, float** d_blob, uint64_t* floats);
+
+/* GSScene::getNumVertices (GSScene.h:37-39). */
+uint64_t gs_scene_num_vertices(const gs_scene* s);
+/* Read back the activated vertices as GSScene::Vertex[n] / cov3DBuffer as float[6n]. */
+int gs_scene_download_vertices(const gs_scene* s, float* vertices);
+int gs_scene_download_cov3d(const gs_scene* s, float* cov3d);
+void gs_scene_destroy(gs_scene* s);
+
+/* ---- renderer: Renderer --------------------------------------------------- */
+
+/* Renderer::initialize (Renderer.cpp:19-31) minus Vulkan/swapchain/GUI: stream,
+ * per-frame buffers, timing events.  The scene must outlive the renderer. */
+int gs_renderer_create(gs_scene* scene, gs_renderer** out);
+void gs_renderer_destroy(gs_renderer* r);
+
+/* Renderer::updateUniforms (Renderer.cpp:719-754), host arithmetic only. */
+int gs_camera_uniforms(const gs_camera* cam, uint32_t width, uint32_t height, gs_uniforms* out);
+
+/* Renderer::draw (Renderer.cpp:366-426): enqueue one frame on the renderer's stream.
+ * d_rgba: width*height*4 floats in HBM (RGB + alpha 1, render.comp:98) or NULL;
+ * d_bgra: width*height*4 bytes B8G8R8A8_UNORM (Swapchain.cpp:22-28) or NULL.
+ * Asynchronous: returns after enqueueing; gs_synchronize() or gs_get_stats() waits.
+ * The instance count stays on the device (no mid-frame readback, cf. Renderer.cpp:391-399);
+ * an overflow of the instance buffers is detected at the next gs_synchronize/gs_get_stats,
+ * which grows them and re-runs the frame (Renderer.cpp:541-563). */
+int gs_render(gs_renderer* r, const gs_uniforms* u, float* d_rgba, uint8_t* d_bgra);
+
+/* Convenience: gs_render into host buffers, synchronous. */
+int gs_render_host(gs_renderer* r, const gs_uniforms* u, float* h_rgba, uint8_t* h_bgra);
+
+int gs_synchronize(gs_renderer* r);
+/* Enable/disable the six hipEvent spans (off: one total span only). */
+int gs_set_timing(gs_renderer* r, int enabled);
+/* Debug: keep a copy of the pre-sort instance arrays (GS_STAGE_INSTANCE_*) of each frame. */
+int gs_set_debug_taps(gs_renderer* r, int enabled);
+/* Renderer::retrieveTimestamps (Renderer.cpp:85-100) for the last frame; synchronizes. */
+int gs_get_stats(gs_renderer* r, gs_frame_stats* out);
+/* Copy a stage buffer of the last frame to host memory; synchronizes. */
+int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes);
+/* The hipStream_t the renderer enqueues on (for HIP-event timing by the caller). */
+void* gs_renderer_stream(gs_renderer* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,178 @@
+"""ctypes binding of oracle/libgs_oracle.so.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+VERTEX_DT = np.dtype([("position", "<f4", 4), ("scale_opacity", "<f4", 4), ("rotation", "<f4", 4),
+                      ("sh", "<f4", 48)])
+ATTR_DT = np.dtype([("conic_opacity", "<f4", 4), ("color_radii", "<f4", 4), ("aabb", "<u4", 4),
+                    ("uv", "<f4", 2), ("depth", "<f4"), ("magic", "<u4")])
+UNIFORMS_DT = np.dtype([("camera_position", "<f4", 4), ("proj_mat", "<f4", 16), ("view_mat", "<f4", 16),
+                        ("width", "<u4"), ("height", "<u4"), ("tan_fovx", "<f4"), ("tan_fovy", "<f4")])
+CAMERA_DT = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("fov", "<f4"),
+                      ("near_plane", "<f4"), ("far_plane", "<f4")])
+assert VERTEX_DT.itemsize == 240 and ATTR_DT.itemsize == 64 and UNIFORMS_DT.itemsize == 160
+
+
+class Stats(C.Structure):
+    _fields_ = [("num_gaussians", C.c_uint64), ("num_visible", C.c_uint64), ("num_instances", C.c_uint64),
+                ("ms", C.c_double * 6)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libgs_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.gso_exp.restype = C.c_float
+        _LIB.gso_exp.argtypes = [C.c_float]
+        _LIB.gso_render_frame.restype = C.c_int
+        _LIB.gso_load_ply.restype = C.c_int
+        _LIB.gso_num_threads.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_camera(position=(0, 0, 0), rotation=(1, 0, 0, 0), fov=45.0, near=0.1, far=1000.0):
+    """Renderer::Camera defaults, src/Renderer.h:79-85."""
+    cam = np.zeros(1, CAMERA_DT)
+    cam["position"] = position
+    cam["rotation"] = rotation
+    cam["fov"], cam["near_plane"], cam["far_plane"] = fov, near, far
+    return cam
+
+
+def camera_uniforms(cam, width, height):
+    out = np.zeros(1, UNIFORMS_DT)
+    lib().gso_camera_uniforms(_p(cam), C.c_uint32(width), C.c_uint32(height), _p(out))
+    return out
+
+
+def exp(x):
+    x = np.asarray(x, np.float32)
+    return np.array([lib().gso_exp(float(v)) for v in x.ravel()], np.float32).reshape(x.shape)
+
+
+def activate_records(records):
+    records = np.ascontiguousarray(records, np.float32).reshape(-1, 62)
+    out = np.zeros(len(records), VERTEX_DT)
+    lib().gso_activate_records(_p(records), C.c_uint64(len(records)), _p(out))
+    return out
+
+
+def load_ply(path):
+    ptr = C.c_void_p()
+    n = C.c_uint64()
+    rc = lib().gso_load_ply(path.encode(), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"gso_load_ply({path}) failed: {rc}")
+    buf = (C.c_char * (n.value * VERTEX_DT.itemsize)).from_address(ptr.value)
+    out = np.frombuffer(buf, VERTEX_DT).copy()
+    lib().gso_free(ptr)
+    return out
+
+
+def cov3d(verts):
+    out = np.zeros((len(verts), 6), np.float32)
+    lib().gso_cov3d(_p(verts), C.c_uint64(len(verts)), _p(out))
+    return out
+
+
+def preprocess(verts, cov, uniforms):
+    n = len(verts)
+    attr = np.zeros(n, ATTR_DT)
+    tiles = np.zeros(n, np.uint32)
+    lib().gso_preprocess(_p(verts), _p(cov), C.c_uint64(n), _p(uniforms), _p(attr), _p(tiles))
+    return attr, tiles
+
+
+def inclusive_scan(tiles):
+    out = np.zeros_like(tiles)
+    lib().gso_inclusive_scan(_p(tiles), C.c_uint64(len(tiles)), _p(out))
+    return out
+
+
+def duplicate(attr, prefix, tile_x):
+    d = int(prefix[-1]) if len(prefix) else 0
+    keys = np.zeros(d, np.uint64)
+    payload = np.zeros(d, np.uint32)
+    lib().gso_duplicate(_p(attr), _p(prefix), C.c_uint64(len(attr)), C.c_uint32(tile_x), _p(keys), _p(payload))
+    return keys, payload
+
+
+def sort_pairs(keys, payload):
+    keys, payload = keys.copy(), payload.copy()
+    lib().gso_sort_pairs(_p(keys), _p(payload), C.c_uint64(len(keys)))
+    return keys, payload
+
+
+def tile_boundary(keys, num_tiles):
+    out = np.zeros(2 * num_tiles, np.uint32)
+    lib().gso_tile_boundary(_p(keys), C.c_uint64(len(keys)), _p(out), C.c_uint64(num_tiles))
+    return out
+
+
+def render(attr, boundaries, payload, width, height):
+    rgba = np.zeros((height, width, 4), np.float32)
+    lib().gso_render(_p(attr), _p(boundaries), _p(payload), C.c_uint32(width), C.c_uint32(height), _p(rgba))
+    return rgba
+
+
+def render_frame(verts, cov, uniforms, want_image=True):
+    """Whole frame in Renderer::draw order; returns (rgba or None, Stats)."""
+    h, w = int(uniforms["height"][0]), int(uniforms["width"][0])
+    rgba = np.zeros((h, w, 4), np.float32) if want_image else None
+    st = Stats()
+    rc = lib().gso_render_frame(_p(verts), _p(cov), C.c_uint64(len(verts)), _p(uniforms),
+                                _p(rgba) if want_image else None, C.byref(st))
+    if rc != 0:
+        raise MemoryError("gso_render_frame")
+    return rgba, st
+
+
+def pack_bgra8(rgba):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    out = np.zeros(rgba.shape[:-1] + (4,), np.uint8)
+    lib().gso_pack_bgra8(_p(rgba), C.c_uint64(rgba.size // 4), _p(out))
+    return out
+
+
+def stages(verts, uniforms):
+    """All per-stage outputs for parity taps."""
+    w, h = int(uniforms["width"][0]), int(uniforms["height"][0])
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    cov = cov3d(verts)
+    attr, tiles = preprocess(verts, cov, uniforms)
+    prefix = inclusive_scan(tiles)
+    keys, payload = duplicate(attr, prefix, tx)
+    skeys, spayload = sort_pairs(keys, payload)
+    bounds = tile_boundary(skeys, tx * ty)
+    img = render(attr, bounds, spayload, w, h)
+    return dict(cov3d=cov, attr=attr, tiles=tiles, prefix=prefix, keys=keys, payload=payload,
+                sorted_keys=skeys, sorted_payload=spayload, boundaries=bounds, image=img)
+
+
+def num_threads():
+    return lib().gso_num_threads()
+
+
+def set_num_threads(n):
+    lib().gso_set_num_threads(C.c_int(n))
