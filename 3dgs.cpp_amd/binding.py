@@ -33,6 +33,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_scene_load_ply", "gs_scene_fr
            "gs_scene_num_vertices", "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
            "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_debug_taps",
+           "gs_set_frames_in_flight", "gs_get_timing_totals",
            "gs_get_stats", "gs_debug_download", "gs_renderer_stream"]
 
 
@@ -202,6 +203,16 @@ class Renderer:
 
     def set_debug_taps(self, enabled):
         _check(lib().gs_set_debug_taps(self._h, C.c_int(int(enabled))))
+
+    def set_frames_in_flight(self, frames):
+        _check(lib().gs_set_frames_in_flight(self._h, C.c_int(int(frames))))
+
+    def timing_totals(self, reset=True):
+        """(sums of per-pass ms as FrameStats, number of frames summed)."""
+        st = FrameStats()
+        n = C.c_uint64()
+        _check(lib().gs_get_timing_totals(self._h, C.byref(st), C.byref(n), C.c_int(int(reset))))
+        return st, n.value
 
     def stats(self):
         st = FrameStats()

@@ -175,7 +175,19 @@ std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
 // ------------------------------------------------------------------------------------------
 // gs_renderer
 // ------------------------------------------------------------------------------------------
+struct FrameSlot {
+    gs_uniforms u{};
+    float* rgba = nullptr;
+    uint8_t* bgra = nullptr;
+    hipEvent_t ev[8] = {};
+    hipEvent_t done = nullptr;
+    gs::Counters* h_counters = nullptr;  // pinned
+    bool timed = false;
+};
+
 struct gs_renderer {
+    static constexpr int kMaxInFlight = 4;
+
     gs_scene* scene = nullptr;
     hipStream_t stream = nullptr;
     bool timing = true;
@@ -195,17 +207,21 @@ struct gs_renderer {
     DevBuf<uint32_t> ikeys[2], ivals[2];
     DevBuf<uint32_t> ranges;
     DevBuf<gs::Counters> counters;
-    gs::Counters* h_counters = nullptr;  // pinned
 
-    hipEvent_t ev[8] = {};
-    // last frame (for overflow retry and taps)
-    gs_uniforms last_u{};
-    float* last_rgba = nullptr;
-    uint8_t* last_bgra = nullptr;
-    bool frame_pending = false;
+    // frames in flight: a ring of descriptors, all enqueued on `stream` (so device buffers are
+    // reused in stream order); the host only waits when the ring is full or on gs_synchronize.
+    FrameSlot slots[kMaxInFlight];
+    int in_flight_limit = 1;  // the reference has FRAMES_IN_FLIGHT 1 (VulkanContext.h:6)
+    uint64_t frames_enqueued = 0;
+    int pending = 0;
+
+    gs_frame_stats last{};  // stats of the most recently retired frame
     bool have_frame = false;
     uint32_t retries = 0;
-    uint32_t* sorted_tile = nullptr;  // result buffers of the last frame
+    double total_ms[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t total_frames = 0;
+
+    uint32_t* sorted_tile = nullptr;  // result buffers of the last enqueued frame
     uint32_t* sorted_gid = nullptr;
     uint32_t* inst_tile = nullptr;
     uint32_t* inst_gid = nullptr;
@@ -213,9 +229,12 @@ struct gs_renderer {
     uint64_t num_tiles = 0;
 
     ~gs_renderer() {
-        for (auto& e : ev)
-            if (e) (void)hipEventDestroy(e);
-        if (h_counters) (void)hipHostFree(h_counters);
+        for (auto& sl : slots) {
+            for (auto& e : sl.ev)
+                if (e) (void)hipEventDestroy(e);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+        }
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -230,7 +249,12 @@ struct gs_renderer {
     void init() {
         HIP_CHECK(hipSetDevice(scene->device));
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+        for (auto& sl : slots) {
+            for (auto& e : sl.ev) HIP_CHECK(hipEventCreate(&e));
+            HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(gs::Counters), hipHostMallocDefault));
+            *sl.h_counters = gs::Counters{};
+        }
         const size_t n = scene->n;
         tiles.alloc(n);
         depth.alloc(n);
@@ -249,19 +273,23 @@ struct gs_renderer {
         digit_total.alloc(256);
         scan_partial.alloc(gs::kScanBlocks);
         counters.alloc(1);
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters), sizeof(gs::Counters), hipHostMallocDefault));
-        *h_counters = gs::Counters{};
         const uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(n));
         set_capacity(static_cast<uint32_t>(std::min<uint64_t>(want, 0xFFFFF000ull)));
     }
 
     void enqueue(const gs_uniforms& u, float* d_rgba, uint8_t* d_bgra) {
         HIP_CHECK(hipSetDevice(scene->device));
+        FrameSlot& sl = slots[frames_enqueued % kMaxInFlight];
+        hipEvent_t* ev = sl.ev;
         const uint32_t n = static_cast<uint32_t>(scene->n);
         const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
-        num_tiles = static_cast<uint64_t>(tx) * ty;
         if (tx > 65535 || ty > 65535) throw Error(GS_ERR_INVALID, "resolution too large (tile box is 16-bit)");
-        ranges.ensure(2 * num_tiles);
+        const uint64_t nt = static_cast<uint64_t>(tx) * ty;
+        if (2 * nt > ranges.n) {  // resize: wait for queued frames that still use the old buffer
+            drain();
+            ranges.alloc(2 * nt);
+        }
+        num_tiles = nt;
 
         gs::SceneView sv{scene->blob, scene->cov3d.p, n};
         gs::AttrView av{tiles.p, depth.p, radius.p, aabb.p, conic_op.p, uv_rg.p, bch.p};
@@ -362,30 +390,83 @@ struct gs_renderer {
         // ---- blend ----
         gs::launch_blend(ranges.p, sorted_gid, av, u.width, u.height, d_rgba, d_bgra, stream);
         HIP_CHECK(hipEventRecord(ev[7], stream));
-        HIP_CHECK(hipMemcpyAsync(h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipEventRecord(sl.done, stream));
         HIP_CHECK(hipGetLastError());
 
-        last_u = u;
-        last_rgba = d_rgba;
-        last_bgra = d_bgra;
-        frame_pending = true;
-        have_frame = true;
+        sl.u = u;
+        sl.rgba = d_rgba;
+        sl.bgra = d_bgra;
+        sl.timed = timing;
+        ++frames_enqueued;
+        ++pending;
     }
 
-    // Wait for the frame; on instance-buffer overflow grow and re-run (Renderer.cpp:541-563).
-    void finish() {
-        if (!frame_pending) return;
-        for (int attempt = 0;; ++attempt) {
+    FrameSlot& oldest() { return slots[(frames_enqueued - pending) % kMaxInFlight]; }
+
+    // Wait for the oldest queued frame; record its stats; on instance-buffer overflow grow the
+    // buffers and re-run it and every frame queued behind it (Renderer.cpp:541-563 retries too).
+    void retire_oldest() {
+        FrameSlot& sl = oldest();
+        HIP_CHECK(hipEventSynchronize(sl.done));
+        if (sl.h_counters->overflow) {
             HIP_CHECK(hipStreamSynchronize(stream));
-            frame_pending = false;
-            if (!h_counters->overflow) return;
-            if (attempt >= 4) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
-            const uint64_t need = static_cast<uint64_t>(h_counters->instances) + h_counters->instances / 8 + 4096;
+            struct Redo {
+                gs_uniforms u;
+                float* rgba;
+                uint8_t* bgra;
+            };
+            std::vector<Redo> redo;
+            uint64_t need = 0;
+            for (int k = 0; k < pending; ++k) {
+                FrameSlot& q = slots[(frames_enqueued - pending + k) % kMaxInFlight];
+                redo.push_back({q.u, q.rgba, q.bgra});
+                need = std::max<uint64_t>(need, q.h_counters->instances);
+            }
+            need = need + need / 8 + 4096;
             if (need > 0xFFFFF000ull) throw Error(GS_ERR_OVERFLOW, "more than 2^32 tile instances");
+            if (retries > 64) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
+            frames_enqueued -= pending;
+            pending = 0;
             set_capacity(static_cast<uint32_t>(need));
             ++retries;
-            enqueue(last_u, last_rgba, last_bgra);
+            for (const Redo& f : redo) enqueue(f.u, f.rgba, f.bgra);
+            return;
         }
+        gs_frame_stats st{};
+        st.num_gaussians = scene->n;
+        st.num_visible = sl.h_counters->visible;
+        st.num_instances = sl.h_counters->instances;
+        st.instance_capacity = capacity;
+        auto span = [&](int a, int b) {
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, sl.ev[a], sl.ev[b]));
+            return ms;
+        };
+        st.ms_total = span(0, 7);
+        if (sl.timed) {
+            st.ms_preprocess = span(0, 1);
+            st.ms_sort = span(1, 2) + span(4, 5);
+            st.ms_prefix_sum = span(2, 3);
+            st.ms_preprocess_sort = span(3, 4);
+            st.ms_tile_boundary = span(5, 6);
+            st.ms_render = span(6, 7);
+        }
+        st.retries = retries;
+        last = st;
+        have_frame = true;
+        const float v[7] = {st.ms_preprocess, st.ms_prefix_sum, st.ms_preprocess_sort, st.ms_sort,
+                            st.ms_tile_boundary, st.ms_render, st.ms_total};
+        for (int k = 0; k < 7; ++k) total_ms[k] += v[k];
+        ++total_frames;
+        --pending;
+    }
+
+    void make_room() {
+        while (pending >= in_flight_limit) retire_oldest();
+    }
+    void drain() {
+        while (pending > 0) retire_oldest();
     }
 };
 
@@ -526,7 +607,7 @@ int gs_render(gs_renderer* r, const gs_uniforms* u, float* d_rgba, uint8_t* d_bg
     return guarded([&] {
         if (!r || !u) throw Error(GS_ERR_INVALID, "null argument");
         if (u->width == 0 || u->height == 0) throw Error(GS_ERR_INVALID, "empty framebuffer");
-        r->finish();  // one frame in flight; resolves a pending overflow first
+        r->make_room();  // at most in_flight_limit frames queued; resolves pending overflows first
         r->enqueue(*u, d_rgba, d_bgra);
     });
 }
@@ -541,27 +622,25 @@ int gs_render_host(gs_renderer* r, const gs_uniforms* u, float* h_rgba, uint8_t*
         DevBuf<uint8_t> d_bgra;
         if (h_rgba) d_rgba.alloc(px * 4);
         if (h_bgra) d_bgra.alloc(px * 4);
-        r->finish();
+        r->drain();
         r->enqueue(*u, h_rgba ? d_rgba.p : nullptr, h_bgra ? d_bgra.p : nullptr);
-        r->finish();
+        r->drain();
         if (h_rgba) HIP_CHECK(hipMemcpy(h_rgba, d_rgba.p, px * 4 * sizeof(float), hipMemcpyDeviceToHost));
         if (h_bgra) HIP_CHECK(hipMemcpy(h_bgra, d_bgra.p, px * 4, hipMemcpyDeviceToHost));
-        r->last_rgba = nullptr;  // temporaries die here
-        r->last_bgra = nullptr;
     });
 }
 
 int gs_synchronize(gs_renderer* r) {
     return guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "null argument");
-        r->finish();
+        r->drain();
     });
 }
 
 int gs_set_timing(gs_renderer* r, int enabled) {
     return guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "null argument");
-        r->finish();
+        r->drain();
         r->timing = enabled != 0;
     });
 }
@@ -569,35 +648,47 @@ int gs_set_timing(gs_renderer* r, int enabled) {
 int gs_set_debug_taps(gs_renderer* r, int enabled) {
     return guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "null argument");
-        r->finish();
+        r->drain();
         r->keep_taps = enabled != 0;
+    });
+}
+
+int gs_set_frames_in_flight(gs_renderer* r, int frames) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "null argument");
+        if (frames < 1 || frames > gs_renderer::kMaxInFlight) throw Error(GS_ERR_INVALID, "frames in flight must be 1..4");
+        r->drain();
+        r->in_flight_limit = frames;
     });
 }
 
 int gs_get_stats(gs_renderer* r, gs_frame_stats* out) {
     return guarded([&] {
         if (!r || !out) throw Error(GS_ERR_INVALID, "null argument");
-        r->finish();
-        *out = gs_frame_stats{};
+        r->drain();
+        *out = r->last;
         out->num_gaussians = r->scene->n;
         out->instance_capacity = r->capacity;
         out->retries = r->retries;
-        if (!r->have_frame) return;
-        out->num_visible = r->h_counters->visible;
-        out->num_instances = r->h_counters->instances;
-        auto span = [&](int a, int b) {
-            float ms = 0.0f;
-            HIP_CHECK(hipEventElapsedTime(&ms, r->ev[a], r->ev[b]));
-            return ms;
-        };
-        out->ms_total = span(0, 7);
-        if (r->timing) {
-            out->ms_preprocess = span(0, 1);
-            out->ms_sort = span(1, 2) + span(4, 5);
-            out->ms_prefix_sum = span(2, 3);
-            out->ms_preprocess_sort = span(3, 4);
-            out->ms_tile_boundary = span(5, 6);
-            out->ms_render = span(6, 7);
+    });
+}
+
+int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset) {
+    return guarded([&] {
+        if (!r || !sum || !frames) throw Error(GS_ERR_INVALID, "null argument");
+        r->drain();
+        *sum = r->last;
+        sum->ms_preprocess = static_cast<float>(r->total_ms[0]);
+        sum->ms_prefix_sum = static_cast<float>(r->total_ms[1]);
+        sum->ms_preprocess_sort = static_cast<float>(r->total_ms[2]);
+        sum->ms_sort = static_cast<float>(r->total_ms[3]);
+        sum->ms_tile_boundary = static_cast<float>(r->total_ms[4]);
+        sum->ms_render = static_cast<float>(r->total_ms[5]);
+        sum->ms_total = static_cast<float>(r->total_ms[6]);
+        *frames = r->total_frames;
+        if (reset) {
+            for (double& v : r->total_ms) v = 0.0;
+            r->total_frames = 0;
         }
     });
 }
@@ -605,10 +696,10 @@ int gs_get_stats(gs_renderer* r, gs_frame_stats* out) {
 int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
     return guarded([&] {
         if (!r || !dst) throw Error(GS_ERR_INVALID, "null argument");
-        r->finish();
+        r->drain();
         if (!r->have_frame) throw Error(GS_ERR_INVALID, "no frame rendered yet");
-        const uint64_t n = r->scene->n, v = r->h_counters->visible;
-        const uint64_t d = std::min<uint64_t>(r->h_counters->instances, r->capacity);
+        const uint64_t n = r->scene->n, v = r->last.num_visible;
+        const uint64_t d = std::min<uint64_t>(r->last.num_instances, r->capacity);
         const void* src = nullptr;
         uint64_t size = 0;
         switch (stage) {

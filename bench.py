@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the splat hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one frame: preprocess -> depth order -> scan -> duplicate -> tile sort -> tile ranges ->
+blend, over the synthetic scene S(1e6) at 1920x1080 (BASELINE configs[1]); the scene is resident in
+HBM before the timed region and the RGBA32F frame stays in HBM.  With N > 1 the scene blob is
+broadcast once over RCCL/xGMI and every rank renders its own camera pose (configs[3]): no per-frame
+collective, weak scaling, value = N*K frames / max-over-ranks time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant pass
+and `cpu_baseline` (the oracle -- CPU restatement of the reference shaders -- on the host cores).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algorithmic_bytes(n, v, d, t, p):
+    """Implementation-independent HBM bytes per frame and pass."""
+    bits = max(1, math.ceil(math.log2(max(t, 2))))
+    tile_passes = math.ceil(bits / 8)
+    return {
+        # pos 12 + cov3d 24 per Gaussian; opacity 4 + SH 192 per visible; 52 B of attributes out; tiles 4
+        "preprocess": n * (12 + 24) + v * (4 + 192) + v * 52 + n * 4,
+        "prefix_sum": 8 * v,
+        "preprocess_sort": v * 20 + d * 8,
+        # depth order: 4 passes over V (key+id in, key+id out) + histogram reads;
+        # tile sort: passes over D (tile+id in/out) + histogram reads
+        "sort": 4 * (4 + 16) * v + tile_passes * (4 + 16) * d,
+        "tile_boundary": 4 * d + 8 * t,
+        "render": 40 * d + 16 * p,
+    }
+
+
+def yaw_quat(deg):
+    """Rotation about the world y axis (w, x, y, z)."""
+    a = math.radians(deg) / 2.0
+    return (math.cos(a), 0.0, math.sin(a), 0.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--gaussians", type=int, default=int(os.environ.get("GS_BENCH_N", 1_000_000)))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames-in-flight", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bgra8", action="store_true", help="also write the B8G8R8A8_UNORM image")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    pkg = entry.load_package()
+    n, w, h = args.gaussians, args.width, args.height
+
+    # ---- scene: built on rank 0, broadcast as one packed SoA blob (59 floats / Gaussian) ----
+    blob = torch.empty(59 * n, dtype=torch.float32, device=dev)
+    if rank == 0:
+        rec = pkg.synth.synth_records(n, seed=0, kind="S")
+        scene0 = pkg.Scene.from_records(rec, device=local_rank)  # GSScene::load path (activations on host)
+        src, floats = scene0.blob()
+        assert floats == blob.numel()
+        hip = ctypes.CDLL("libamdhip64.so")
+        rc = hip.hipMemcpy(ctypes.c_void_p(blob.data_ptr()), ctypes.c_void_p(src), ctypes.c_size_t(floats * 4),
+                           ctypes.c_int(3))  # hipMemcpyDeviceToDevice
+        assert rc == 0
+        scene0.close()
+        del rec
+    if world > 1:
+        dist.broadcast(blob, src=0)
+    torch.cuda.synchronize()
+    scene = pkg.Scene.from_device_blob(blob.data_ptr(), n, device=local_rank, keepalive=blob)
+    rend = pkg.Renderer(scene)
+    rend.set_frames_in_flight(args.frames_in_flight)
+
+    cam = pkg.make_camera(rotation=yaw_quat(5.0 * rank))  # pose k = default camera yawed k*5 deg
+    u = pkg.camera_uniforms(cam, w, h)
+    out = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    out8 = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if args.bgra8 else None
+    p8 = out8.data_ptr() if out8 is not None else 0
+
+    def sync_all():
+        rend.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        rend.render(u, out.data_ptr(), p8)
+    sync_all()
+    rend.timing_totals(reset=True)
+
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rend.render(u, out.data_ptr(), p8)
+    rend.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    sums, frames = rend.timing_totals(reset=True)
+    st = rend.stats()
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        T = ((w + 15) // 16) * ((h + 15) // 16)
+        nbytes = algorithmic_bytes(st.num_gaussians, st.num_visible, st.num_instances, T, w * h)
+        names = ["preprocess", "prefix_sum", "preprocess_sort", "sort", "tile_boundary", "render"]
+        ms = {k: getattr(sums, "ms_" + k) / max(frames, 1) for k in names}
+        per_pass = {k: {"ms": round(ms[k], 4), "alg_MB": round(nbytes[k] / 1e6, 2),
+                        "GBps": round(nbytes[k] / 1e9 / (ms[k] * 1e-3), 1) if ms[k] > 0 else None} for k in names}
+        dom = max(names, key=lambda k: ms[k])
+        achieved = nbytes[dom] / 1e9 / (ms[dom] * 1e-3)
+        result = {
+            "metric": "frames/sec at 1920x1080, 1M Gaussians",
+            "value": round(fps, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"S({n}) synthetic Gaussians, {w}x{h}, degree-3 SH, one camera pose per GPU "
+                                   f"(BASELINE configs[1]; configs[3] when n_gpus>1)",
+                       "gaussians": int(st.num_gaussians), "visible": int(st.num_visible),
+                       "instances": int(st.num_instances), "tiles": T, "output": "rgba32f" + ("+bgra8" if args.bgra8 else ""),
+                       "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}"},
+            "gpu_ms_per_frame": round(sums.ms_total / max(frames, 1), 4),
+            "passes": per_pass,
+            "roofline": {"kernel": {"render": "k_blend"}.get(dom, dom), "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "blend is FP32-VALU bound, not HBM bound (DESIGN.md §5); frac is the HBM view"},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(n, w, h)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(n, w, h):
+    """The oracle (CPU restatement of the reference shaders, all host cores via OpenMP) on one frame of
+    the same workload -- a bounded sample (about 10-30 s of CPU work).  Baseline only."""
+    oracle = entry.load_oracle()
+    pkg = entry.load_package()
+    rec = pkg.synth.synth_records(n, seed=0, kind="S")
+    verts = oracle.activate_records(rec)
+    cov = oracle.cov3d(verts)
+    u = oracle.camera_uniforms(oracle.default_camera(), w, h)
+    t0 = time.perf_counter()
+    _, st = oracle.render_frame(verts, cov, u, want_image=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"1 frame of the same workload (N={n}, {w}x{h}, D={st.num_instances}), {dt:.1f} s wall",
+            "ms": [round(x, 2) for x in st.ms]}
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,13 @@ int gs_render_host(gs_renderer* r, const gs_uniforms* u, float* h_rgba, uint8_t*
 int gs_synchronize(gs_renderer* r);
 /* Enable/disable the six hipEvent spans (off: one total span only). */
 int gs_set_timing(gs_renderer* r, int enabled);
+/* Frames that may be queued on the stream before gs_render blocks (1..4, default 1 like
+ * FRAMES_IN_FLIGHT, VulkanContext.h:6).  With k > 1 the host enqueues frame i+1 while frame i
+ * runs; an overflowed frame and everything queued behind it are re-run after growing. */
+int gs_set_frames_in_flight(gs_renderer* r, int frames);
+/* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
+ * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
+int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset);
 /* Debug: keep a copy of the pre-sort instance arrays (GS_STAGE_INSTANCE_*) of each frame. */
 int gs_set_debug_taps(gs_renderer* r, int enabled);
 /* Renderer::retrieveTimestamps (Renderer.cpp:85-100) for the last frame; synchronizes. */
