@@ -728,11 +728,42 @@ void launch_tile_ranges(const uint32_t* sorted_tile, const uint32_t* n, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------
-// blend.  One 256-thread workgroup per 16x16 tile; each wave owns an 8x8 pixel quadrant.
+// blend.  One 256-thread workgroup per 16x16 tile; wave q owns the 8x8 pixel quadrant q.
 // The tile's list is fetched in batches of 256 entries: thread t gathers entry t's record
-// (9 floats) once into LDS, then all pixels walk the batch with broadcast LDS reads.
+// (9 floats) once into LDS and classifies it against the four quadrants; each wave then walks
+// only the entries that can reach its quadrant, in list order, with broadcast LDS reads.
 // render.comp:61-98 semantics, operation order as written there.
+//
+// Exactness of the culling: an entry contributes to a pixel only if alpha = min(0.99, o*exp(power))
+// >= 1/255, i.e. power >= -tau with tau = ln(255*o).  {power >= -tau} is the ellipse
+// d^T C d <= 2 tau around uv (C = conic); its axis-aligned half extents are sqrt(2 tau C^-1_xx),
+// sqrt(2 tau C^-1_yy).  A quadrant whose pixel rectangle misses that box (inflated by 0.1 % + 0.01
+// px, against ~1e-6 relative rounding in power/exp) holds only pixels for which the shader executes
+// `continue`, so skipping the entry for that wave changes nothing.  The same bound gives a per-entry
+// lower limit on power below which exp() need not be evaluated.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quadrant_mask(const float4 co, float u, float v, float x0, float y0,
+                                                  float* pmin) {
+    // tau with slack; all comparisons are written so that NaN falls on the conservative side
+    const float tau = __logf(255.0f * co.w);
+    *pmin = -(fmaxf(tau, 0.0f) * 1.001f + 1e-3f);
+    if (tau <= -1e-3f) return 0u;  // o*exp(p) < 1/255 for every p <= 0
+    const float t2 = 2.0f * (fmaxf(tau, 0.0f) * 1.001f + 1e-3f);
+    const float det = co.x * co.z - co.y * co.y;
+    const float hx = sqrtf(t2 * co.z / det) * 1.001f + 0.01f;
+    const float hy = sqrtf(t2 * co.x / det) * 1.001f + 0.01f;
+    const bool out_x0 = (u + hx < x0) || (u - hx > x0 + 7.0f);
+    const bool out_x1 = (u + hx < x0 + 8.0f) || (u - hx > x0 + 15.0f);
+    const bool out_y0 = (v + hy < y0) || (v - hy > y0 + 7.0f);
+    const bool out_y1 = (v + hy < y0 + 8.0f) || (v - hy > y0 + 15.0f);
+    uint32_t m = 0;
+    m |= (!out_x0 && !out_y0) ? 1u : 0u;
+    m |= (!out_x1 && !out_y0) ? 2u : 0u;
+    m |= (!out_x0 && !out_y1) ? 4u : 0u;
+    m |= (!out_x1 && !out_y1) ? 8u : 0u;
+    return m;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ sorted_gid,
                                                  const float4* __restrict__ conic_op,
@@ -741,11 +772,13 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                                                  float4* __restrict__ rgba, uchar4* __restrict__ bgra) {
     __shared__ float4 s_co[BLOCK];
     __shared__ float4 s_uv[BLOCK];
-    __shared__ float s_b[BLOCK];
+    __shared__ float2 s_bp[BLOCK];       // b, lower bound on power
+    __shared__ uint32_t s_qm[4][4][2];   // [quadrant][64-entry chunk] 64-bit entry masks (lo, hi)
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const uint32_t px = blockIdx.x * kTile + (w & 1) * 8 + (lane & 7);
-    const uint32_t py = blockIdx.y * kTile + (w >> 1) * 8 + (lane >> 3);
+    const uint32_t tile_x0 = blockIdx.x * kTile, tile_y0 = blockIdx.y * kTile;
+    const uint32_t px = tile_x0 + (w & 1) * 8 + (lane & 7);
+    const uint32_t py = tile_y0 + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < width && py < height;  // render.comp:36-39
     const float fx = (float)px, fy = (float)py;
 
@@ -756,32 +789,61 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     for (uint32_t base = range.x; base < range.y; base += BLOCK) {
         if (__syncthreads_and(done)) break;  // whole tile saturated; also fences LDS reuse
         const uint32_t cnt = min((uint32_t)BLOCK, range.y - base);
+        uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
             const uint32_t g = sorted_gid[base + tid];
-            s_co[tid] = conic_op[g];
-            s_uv[tid] = uv_rg[g];
-            s_b[tid] = bch[g];
+            const float4 co = conic_op[g];
+            const float4 uv = uv_rg[g];
+            float pmin;
+            qm = quadrant_mask(co, uv.x, uv.y, (float)tile_x0, (float)tile_y0, &pmin);
+            s_co[tid] = co;
+            s_uv[tid] = uv;
+            s_bp[tid] = make_float2(bch[g], pmin);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t bal = __ballot((qm >> q) & 1u);
+            if (lane == 0) {
+                s_qm[q][w][0] = (uint32_t)bal;
+                s_qm[q][w][1] = (uint32_t)(bal >> 32);
+            }
         }
         __syncthreads();
-        if (!done) {
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4 co = s_co[k];
-                const float4 uv = s_uv[k];
-                const float dx = uv.x - fx;
-                const float dy = uv.y - fy;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;  // :66
-                if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, co.w * gs_exp(power));  // :77
-                if (alpha < 1.0f / 255.0f) continue;
-                const float test_T = T * (1 - alpha);
-                if (test_T < 0.0001f) {  // :82-85
-                    done = true;
-                    break;
+        if (__ballot(!done) != 0) {
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t lo = __builtin_amdgcn_readfirstlane(s_qm[w][c][0]);
+                const uint32_t hi = __builtin_amdgcn_readfirstlane(s_qm[w][c][1]);
+                uint64_t bm = ((uint64_t)hi << 32) | lo;
+                while (bm) {
+                    const int k = c * WAVE + (__ffsll((unsigned long long)bm) - 1);
+                    bm &= bm - 1;
+                    if (!done) {
+                        const float4 co = s_co[k];
+                        const float4 uv = s_uv[k];
+                        const float2 bp = s_bp[k];
+                        const float dx = uv.x - fx;
+                        const float dy = uv.y - fy;
+                        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;  // :66
+                        if (!(power > 0.0f) && !(power < bp.y)) {
+                            const float alpha = fminf(0.99f, co.w * gs_exp(power));  // :77
+                            if (!(alpha < 1.0f / 255.0f)) {
+                                const float test_T = T * (1 - alpha);
+                                if (test_T < 0.0001f) {  // :82-85
+                                    done = true;
+                                } else {
+                                    c0 += uv.z * alpha * T;  // :87
+                                    c1 += uv.w * alpha * T;
+                                    c2 += bp.x * alpha * T;
+                                    T = test_T;
+                                }
+                            }
+                        }
+                    }
+                    if (__ballot(!done) == 0) {
+                        bm = 0;
+                        c = 4;
+                    }
                 }
-                c0 += uv.z * alpha * T;  // :87
-                c1 += uv.w * alpha * T;
-                c2 += s_b[k] * alpha * T;
-                T = test_T;
             }
         }
     }
