@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgs3d_hip.so")
+LIB_PATH = os.environ.get("GS3D_HIP_LIB", os.path.join(_HERE, "libgs3d_hip.so"))  # override: instrumented builds
 
 UNIFORMS_DT = np.dtype([("camera_position", "<f4", 4), ("proj_mat", "<f4", 16), ("view_mat", "<f4", 16),
                         ("width", "<u4"), ("height", "<u4"), ("tan_fovx", "<f4"), ("tan_fovy", "<f4")])

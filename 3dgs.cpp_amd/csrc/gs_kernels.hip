@@ -764,6 +764,14 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4 co, float u, floa
     return m;
 }
 
+#ifdef GS_BLEND_STATS
+// debug instrumentation (separate build, never the shipped library)
+__device__ unsigned long long g_blend_stats[8];
+#define STAT_ADD(i, v) do { const unsigned long long v_ = (unsigned long long)(v); const bool first_ = (__ffsll((unsigned long long)__ballot(true)) - 1) == lane; if (first_) atomicAdd(&g_blend_stats[i], v_); } while (0)
+#else
+#define STAT_ADD(i, v) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ sorted_gid,
                                                  const float4* __restrict__ conic_op,
@@ -809,6 +817,12 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
             }
         }
         __syncthreads();
+        STAT_ADD(0, 1);                                 // wave-batches staged
+        STAT_ADD(1, __popcll(__ballot(qm != 0)));       // entries with any quadrant
+        STAT_ADD(6, (uint32_t)tid < cnt ? min(64u, cnt - (uint32_t)w * 64u) : 0);  // entries staged
+        // Walk this quadrant's entries in list order.  The body is predicated (selects) rather than
+        // branched: nested divergent branches cost ~40 scalar exec-mask instructions per entry and the
+        // CU's single scalar unit, not the VALU, becomes the limiter.  One uniform branch skips exp().
         if (__ballot(!done) != 0) {
             for (int c = 0; c < 4; ++c) {
                 const uint32_t lo = __builtin_amdgcn_readfirstlane(s_qm[w][c][0]);
@@ -817,31 +831,35 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                 while (bm) {
                     const int k = c * WAVE + (__ffsll((unsigned long long)bm) - 1);
                     bm &= bm - 1;
-                    if (!done) {
-                        const float4 co = s_co[k];
-                        const float4 uv = s_uv[k];
-                        const float2 bp = s_bp[k];
-                        const float dx = uv.x - fx;
-                        const float dy = uv.y - fy;
-                        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;  // :66
-                        if (!(power > 0.0f) && !(power < bp.y)) {
-                            const float alpha = fminf(0.99f, co.w * gs_exp(power));  // :77
-                            if (!(alpha < 1.0f / 255.0f)) {
-                                const float test_T = T * (1 - alpha);
-                                if (test_T < 0.0001f) {  // :82-85
-                                    done = true;
-                                } else {
-                                    c0 += uv.z * alpha * T;  // :87
-                                    c1 += uv.w * alpha * T;
-                                    c2 += bp.x * alpha * T;
-                                    T = test_T;
-                                }
-                            }
+                    STAT_ADD(2, 1);                             // (entry, wave) pairs evaluated
+                    STAT_ADD(3, __popcll(__ballot(!done)));     // lanes alive
+                    const float4 co = s_co[k];
+                    const float4 uv = s_uv[k];
+                    const float2 bp = s_bp[k];
+                    const float dx = uv.x - fx;
+                    const float dy = uv.y - fy;
+                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;  // :66
+                    const bool p1 = !done && !(power > 0.0f) && !(power < bp.y);
+                    if (__ballot(p1) != 0) {
+                        STAT_ADD(4, 1);                         // pairs reaching exp
+                        STAT_ADD(5, __popcll(__ballot(p1)));    // lanes needing exp
+                        const float alpha = fminf(0.99f, co.w * gs_exp(power));  // :77
+                        const bool p2 = p1 && !(alpha < 1.0f / 255.0f);
+                        const float test_T = T * (1 - alpha);
+                        const bool kill = p2 && (test_T < 0.0001f);  // :82-85
+                        const bool upd = p2 && !kill;
+                        const float n0 = c0 + uv.z * alpha * T;  // :87
+                        const float n1 = c1 + uv.w * alpha * T;
+                        const float n2 = c2 + bp.x * alpha * T;
+                        c0 = upd ? n0 : c0;
+                        c1 = upd ? n1 : c1;
+                        c2 = upd ? n2 : c2;
+                        T = upd ? test_T : T;
+                        done = done || kill;
+                        if (__ballot(!done) == 0) {
+                            bm = 0;
+                            c = 4;
                         }
-                    }
-                    if (__ballot(!done) == 0) {
-                        bm = 0;
-                        c = 4;
                     }
                 }
             }
@@ -869,5 +887,14 @@ void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const Attr
                        sorted_gid, av.conic_op, av.uv_rg, av.b, width, height, tx,
                        reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra));
 }
+
+#ifdef GS_BLEND_STATS
+extern "C" int gs_debug_blend_stats(unsigned long long* out, int reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_stats), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 }  // namespace gs
