@@ -728,40 +728,48 @@ void launch_tile_ranges(const uint32_t* sorted_tile, const uint32_t* n, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------
-// blend.  One 256-thread workgroup per 16x16 tile; wave q owns the 8x8 pixel quadrant q.
-// The tile's list is fetched in batches of 256 entries: thread t gathers entry t's record
-// (9 floats) once into LDS and classifies it against the four quadrants; each wave then walks
-// only the entries that can reach its quadrant, in list order, with broadcast LDS reads.
-// render.comp:61-98 semantics, operation order as written there.
+// blend.  One wave per 8x8 pixel quadrant of a 16x16 tile (4 waves = one workgroup per tile), and the
+// four waves are fully independent: no workgroup barrier anywhere, so a quadrant whose pixels have
+// saturated retires at once and a slow quadrant never stalls its neighbours.
+//
+// Each wave walks its tile's depth-sorted list in chunks of 64 entries: lane l fetches entry l's record
+// (9 floats, gathered through the sorted Gaussian id; the next chunk is prefetched while the current one
+// is blended), tests it against the wave's quadrant, parks it in a wave-private LDS slab, and a 64-bit
+// ballot of the survivors drives a scalar loop that evaluates only those entries, in list order, with
+// broadcast LDS reads.  The per-pixel body is predicated (selects) instead of branched: nested divergent
+// branches cost ~40 scalar exec-mask instructions per entry and saturate the CU's scalar unit.
+//
+// render.comp:61-98 semantics.  Floating-point contract: the shader's expressions with the three
+// multiply-adds that GLSL lets a compiler contract written as explicit FMAs (marked FMA below; the
+// oracle makes the same choice), nothing reassociated.
 //
 // Exactness of the culling: an entry contributes to a pixel only if alpha = min(0.99, o*exp(power))
-// >= 1/255, i.e. power >= -tau with tau = ln(255*o).  {power >= -tau} is the ellipse
-// d^T C d <= 2 tau around uv (C = conic); its axis-aligned half extents are sqrt(2 tau C^-1_xx),
-// sqrt(2 tau C^-1_yy).  A quadrant whose pixel rectangle misses that box (inflated by 0.1 % + 0.01
-// px, against ~1e-6 relative rounding in power/exp) holds only pixels for which the shader executes
-// `continue`, so skipping the entry for that wave changes nothing.  The same bound gives a per-entry
-// lower limit on power below which exp() need not be evaluated.
+// >= 1/255, i.e. power >= -tau with tau = ln(255*o), and -power = q(d) = 0.5 d^T C d (C = conic) is
+// a convex quadratic of d = uv - pixel.  If the minimum of q over the quadrant's pixel rectangle exceeds
+// tau (with 0.1 % + 1e-3 slack against ~1e-6 relative rounding in power/exp/log), every pixel of the
+// quadrant executes `continue` in the shader, so skipping the entry for that wave changes nothing.
+// The same bound gives a per-entry lower limit on power below which exp() need not be evaluated.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t quadrant_mask(const float4 co, float u, float v, float x0, float y0,
-                                                  float* pmin) {
-    // tau with slack; all comparisons are written so that NaN falls on the conservative side
-    const float tau = __logf(255.0f * co.w);
-    *pmin = -(fmaxf(tau, 0.0f) * 1.001f + 1e-3f);
-    if (tau <= -1e-3f) return 0u;  // o*exp(p) < 1/255 for every p <= 0
-    const float t2 = 2.0f * (fmaxf(tau, 0.0f) * 1.001f + 1e-3f);
-    const float det = co.x * co.z - co.y * co.y;
-    const float hx = sqrtf(t2 * co.z / det) * 1.001f + 0.01f;
-    const float hy = sqrtf(t2 * co.x / det) * 1.001f + 0.01f;
-    const bool out_x0 = (u + hx < x0) || (u - hx > x0 + 7.0f);
-    const bool out_x1 = (u + hx < x0 + 8.0f) || (u - hx > x0 + 15.0f);
-    const bool out_y0 = (v + hy < y0) || (v - hy > y0 + 7.0f);
-    const bool out_y1 = (v + hy < y0 + 8.0f) || (v - hy > y0 + 15.0f);
-    uint32_t m = 0;
-    m |= (!out_x0 && !out_y0) ? 1u : 0u;
-    m |= (!out_x1 && !out_y0) ? 2u : 0u;
-    m |= (!out_x0 && !out_y1) ? 4u : 0u;
-    m |= (!out_x1 && !out_y1) ? 8u : 0u;
-    return m;
+
+// min over the pixel rectangle [xa,xb] x [ya,yb] of q(d) = 0.5 (c00 dx^2 + c11 dy^2) + c01 dx dy,
+// d = uv - pixel.  q is convex with its minimum 0 at d = 0: inside the rectangle the answer is 0,
+// otherwise the minimum lies on one of the four edges, where q is a 1-D parabola.
+__device__ __forceinline__ float min_q_rect(float c00, float c01, float c11, float u, float v, float xa,
+                                            float xb, float ya, float yb) {
+    const float dx_lo = u - xb, dx_hi = u - xa, dy_lo = v - yb, dy_hi = v - ya;
+    if (!(dx_lo > 0.0f) && !(dx_hi < 0.0f) && !(dy_lo > 0.0f) && !(dy_hi < 0.0f)) return 0.0f;
+    const float r11 = -c01 * __builtin_amdgcn_rcpf(c11), r00 = -c01 * __builtin_amdgcn_rcpf(c00);
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float a = e ? dx_hi : dx_lo;  // vertical edges: dx fixed, parabola in dy
+        const float t = fminf(fmaxf(r11 * a, dy_lo), dy_hi);
+        best = fminf(best, 0.5f * (c00 * a * a + c11 * t * t) + c01 * a * t);
+        const float b = e ? dy_hi : dy_lo;  // horizontal edges: dy fixed, parabola in dx
+        const float s = fminf(fmaxf(r00 * b, dx_lo), dx_hi);
+        best = fminf(best, 0.5f * (c00 * s * s + c11 * b * b) + c01 * s * b);
+    }
+    return best;  // any point of an edge bounds the true minimum from above: an inexact rcp only loosens the test
 }
 
 #ifdef GS_BLEND_STATS
@@ -772,97 +780,131 @@ __device__ unsigned long long g_blend_stats[8];
 #define STAT_ADD(i, v) do { } while (0)
 #endif
 
+// gs_exp without the lower clamp: every lane whose result is used has power in [-7, 0].
+__device__ __forceinline__ float gs_exp_blend(float x) {
+    const float L2E = 1.44269502162933349609375f;
+    const float MAGIC = 12582912.0f;
+    float tm = __builtin_fmaf(x, L2E, MAGIC);
+    float n = tm - MAGIC;
+    float f = __builtin_fmaf(x, L2E, -n);
+    float p = 0x1.41d332p-13f;
+    p = __builtin_fmaf(p, f, 0x1.5f456ap-10f);
+    p = __builtin_fmaf(p, f, 0x1.3b2dbcp-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6aed4p-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebfbdap-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e430p-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(tm) << 23));
+}
+
+struct BlendEntry {
+    float4 co;  // c00 c01 c11 opacity
+    float4 uv;  // u v r g
+    float b;
+};
+
+__device__ __forceinline__ void blend_fetch(BlendEntry& e, uint32_t g, const float4* __restrict__ conic_op,
+                                            const float4* __restrict__ uv_rg, const float* __restrict__ bch) {
+    e.co = conic_op[g];
+    e.uv = uv_rg[g];
+    e.b = bch[g];
+}
+
 __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ sorted_gid,
                                                  const float4* __restrict__ conic_op,
                                                  const float4* __restrict__ uv_rg, const float* __restrict__ bch,
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
                                                  float4* __restrict__ rgba, uchar4* __restrict__ bgra) {
-    __shared__ float4 s_co[BLOCK];
-    __shared__ float4 s_uv[BLOCK];
-    __shared__ float2 s_bp[BLOCK];       // b, lower bound on power
-    __shared__ uint32_t s_qm[4][4][2];   // [quadrant][64-entry chunk] 64-bit entry masks (lo, hi)
+    __shared__ float4 s_co[4][WAVE];   // wave-private slabs: no cross-wave sharing, no barriers
+    __shared__ float4 s_uv[4][WAVE];
+    __shared__ float2 s_bp[4][WAVE];   // b, lower bound on power
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const uint32_t tile_x0 = blockIdx.x * kTile, tile_y0 = blockIdx.y * kTile;
-    const uint32_t px = tile_x0 + (w & 1) * 8 + (lane & 7);
-    const uint32_t py = tile_y0 + (w >> 1) * 8 + (lane >> 3);
+    const uint32_t qx0 = blockIdx.x * kTile + (w & 1) * 8, qy0 = blockIdx.y * kTile + (w >> 1) * 8;
+    const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < width && py < height;  // render.comp:36-39
     const float fx = (float)px, fy = (float)py;
+    const float rx0 = (float)qx0, ry0 = (float)qy0;
 
     const uint2 range = ranges[blockIdx.x + blockIdx.y * tiles_x];
     float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     bool done = !inside;
 
-    for (uint32_t base = range.x; base < range.y; base += BLOCK) {
-        if (__syncthreads_and(done)) break;  // whole tile saturated; also fences LDS reuse
-        const uint32_t cnt = min((uint32_t)BLOCK, range.y - base);
-        uint32_t qm = 0;
-        if ((uint32_t)tid < cnt) {
-            const uint32_t g = sorted_gid[base + tid];
-            const float4 co = conic_op[g];
-            const float4 uv = uv_rg[g];
-            float pmin;
-            qm = quadrant_mask(co, uv.x, uv.y, (float)tile_x0, (float)tile_y0, &pmin);
-            s_co[tid] = co;
-            s_uv[tid] = uv;
-            s_bp[tid] = make_float2(bch[g], pmin);
+    if (__ballot(!done) != 0 && range.x < range.y) {
+        // software pipeline over 64-entry chunks: ids two chunks ahead, records one chunk ahead
+        BlendEntry nxt;
+        nxt.co = make_float4(0, 0, 0, 0);
+        nxt.uv = make_float4(0, 0, 0, 0);
+        nxt.b = 0;
+        uint32_t g_next = 0;
+        {
+            const uint32_t i0 = range.x + lane;
+            if (i0 < range.y) blend_fetch(nxt, sorted_gid[i0], conic_op, uv_rg, bch);
+            const uint32_t i1 = i0 + WAVE;
+            if (i1 < range.y) g_next = sorted_gid[i1];
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint64_t bal = __ballot((qm >> q) & 1u);
-            if (lane == 0) {
-                s_qm[q][w][0] = (uint32_t)bal;
-                s_qm[q][w][1] = (uint32_t)(bal >> 32);
+        for (uint32_t base = range.x; base < range.y; base += WAVE) {
+            const BlendEntry cur = nxt;
+            const bool have = base + lane < range.y;
+            {   // prefetch: records of chunk +1 (ids already here), ids of chunk +2
+                const uint32_t i1 = base + WAVE + lane;
+                if (i1 < range.y) blend_fetch(nxt, g_next, conic_op, uv_rg, bch);
+                const uint32_t i2 = i1 + WAVE;
+                if (i2 < range.y) g_next = sorted_gid[i2];
             }
-        }
-        __syncthreads();
-        STAT_ADD(0, 1);                                 // wave-batches staged
-        STAT_ADD(1, __popcll(__ballot(qm != 0)));       // entries with any quadrant
-        STAT_ADD(6, (uint32_t)tid < cnt ? min(64u, cnt - (uint32_t)w * 64u) : 0);  // entries staged
-        // Walk this quadrant's entries in list order.  The body is predicated (selects) rather than
-        // branched: nested divergent branches cost ~40 scalar exec-mask instructions per entry and the
-        // CU's single scalar unit, not the VALU, becomes the limiter.  One uniform branch skips exp().
-        if (__ballot(!done) != 0) {
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t lo = __builtin_amdgcn_readfirstlane(s_qm[w][c][0]);
-                const uint32_t hi = __builtin_amdgcn_readfirstlane(s_qm[w][c][1]);
-                uint64_t bm = ((uint64_t)hi << 32) | lo;
-                while (bm) {
-                    const int k = c * WAVE + (__ffsll((unsigned long long)bm) - 1);
-                    bm &= bm - 1;
-                    STAT_ADD(2, 1);                             // (entry, wave) pairs evaluated
-                    STAT_ADD(3, __popcll(__ballot(!done)));     // lanes alive
-                    const float4 co = s_co[k];
-                    const float4 uv = s_uv[k];
-                    const float2 bp = s_bp[k];
-                    const float dx = uv.x - fx;
-                    const float dy = uv.y - fy;
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;  // :66
-                    const bool p1 = !done && !(power > 0.0f) && !(power < bp.y);
-                    if (__ballot(p1) != 0) {
-                        STAT_ADD(4, 1);                         // pairs reaching exp
-                        STAT_ADD(5, __popcll(__ballot(p1)));    // lanes needing exp
-                        const float alpha = fminf(0.99f, co.w * gs_exp(power));  // :77
-                        const bool p2 = p1 && !(alpha < 1.0f / 255.0f);
-                        const float test_T = T * (1 - alpha);
-                        const bool kill = p2 && (test_T < 0.0001f);  // :82-85
-                        const bool upd = p2 && !kill;
-                        const float n0 = c0 + uv.z * alpha * T;  // :87
-                        const float n1 = c1 + uv.w * alpha * T;
-                        const float n2 = c2 + bp.x * alpha * T;
-                        c0 = upd ? n0 : c0;
-                        c1 = upd ? n1 : c1;
-                        c2 = upd ? n2 : c2;
-                        T = upd ? test_T : T;
-                        done = done || kill;
-                        if (__ballot(!done) == 0) {
-                            bm = 0;
-                            c = 4;
-                        }
-                    }
+            // classify entry `lane` of this chunk against the wave's quadrant
+            const float tau = __logf(255.0f * cur.co.w);
+            const float lim = fmaxf(tau, 0.0f) * 1.001f + 1e-3f;
+            bool keep = have && !(tau <= -1e-3f);  // tau <= 0: o*exp(p) < 1/255 for every p <= 0
+            if (keep) {
+                const float mq = min_q_rect(cur.co.x, cur.co.y, cur.co.z, cur.uv.x, cur.uv.y, rx0, rx0 + 7.0f,
+                                            ry0, ry0 + 7.0f);
+                keep = !(mq > lim);  // NaN -> keep
+            }
+            uint64_t bm = __ballot(keep);
+            STAT_ADD(0, 1);
+            STAT_ADD(6, __popcll(__ballot(have)));
+            STAT_ADD(1, __popcll(bm));
+            if (bm == 0) continue;
+            s_co[w][lane] = cur.co;
+            s_uv[w][lane] = cur.uv;
+            s_bp[w][lane] = make_float2(cur.b, -lim);
+
+            while (bm) {
+                const int k = __ffsll((unsigned long long)bm) - 1;
+                bm &= bm - 1;
+                STAT_ADD(2, 1);                             // (entry, wave) pairs evaluated
+                STAT_ADD(3, __popcll(__ballot(!done)));     // lanes alive
+                const float4 co = s_co[w][k];
+                const float4 uv = s_uv[w][k];
+                const float2 bp = s_bp[w][k];
+                const float dx = uv.x - fx;
+                const float dy = uv.y - fy;
+                // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
+                const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);        // FMA
+                const float power = __builtin_fmaf(-(co.y * dx), dy, -0.5f * s);      // FMA
+                const bool p1 = !done && !(power > 0.0f) && !(power < bp.y);
+                if (__ballot(p1) != 0) {
+                    STAT_ADD(4, 1);                         // pairs reaching exp
+                    STAT_ADD(5, __popcll(__ballot(p1)));    // lanes needing exp
+                    const float alpha = fminf(0.99f, co.w * gs_exp_blend(power));  // :77
+                    const bool p2 = p1 && !(alpha < 1.0f / 255.0f);
+                    const float test_T = T * (1 - alpha);
+                    const bool kill = p2 && (test_T < 0.0001f);  // :82-85
+                    const bool upd = p2 && !kill;
+                    const float n0 = __builtin_fmaf(uv.z * alpha, T, c0);  // :87  FMA
+                    const float n1 = __builtin_fmaf(uv.w * alpha, T, c1);
+                    const float n2 = __builtin_fmaf(bp.x * alpha, T, c2);
+                    c0 = upd ? n0 : c0;
+                    c1 = upd ? n1 : c1;
+                    c2 = upd ? n2 : c2;
+                    T = upd ? test_T : T;
+                    done = done || kill;
+                    if (__ballot(!done) == 0) bm = 0;
                 }
             }
+            if (__ballot(!done) == 0) break;
         }
     }
     if (inside) {

@@ -630,15 +630,18 @@ void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const u
                         float dx = a->uv[0] - (float)px;
                         float dy = a->uv[1] - (float)py;
                         const float* co = a->conic_opacity;
-                        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy; /* :66 */
+                        /* :66  -0.5*(co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy with the two
+                         * multiply-adds GLSL allows a compiler to contract written as FMAs */
+                        float s = fmaf(co[2] * dy, dy, co[0] * dx * dx);
+                        float power = fmaf(-(co[1] * dx), dy, -0.5f * s);
                         if (power > 0.0f) continue;
                         float alpha = fminf(0.99f, co[3] * gso_exp(power)); /* :77 */
                         if (alpha < 1.0f / 255.0f) continue;
                         float test_T = T * (1 - alpha);
                         if (test_T < 0.0001f) break; /* :82-85 */
-                        c0 += a->color_radii[0] * alpha * T; /* :87 */
-                        c1 += a->color_radii[1] * alpha * T;
-                        c2 += a->color_radii[2] * alpha * T;
+                        c0 = fmaf(a->color_radii[0] * alpha, T, c0); /* :87, contracted */
+                        c1 = fmaf(a->color_radii[1] * alpha, T, c1);
+                        c2 = fmaf(a->color_radii[2] * alpha, T, c2);
                         T = test_T;
                     }
                     float* o = rgba + ((uint64_t)py * width + px) * 4;

@@ -15,7 +15,10 @@
  *
  * Floating-point contract (shared with the HIP kernels by specification, not
  * by shared code): IEEE-754 binary32, every operation rounded separately in
- * the order written in the shader (compile with -ffp-contract=off), IEEE
+ * the order written in the shader (compile with -ffp-contract=off; the only
+ * fused operations are the explicit fmaf() calls in gso_exp and the three
+ * multiply-adds of render.comp:66,87 that GLSL permits a compiler to contract
+ * -- contraction, never reassociation), IEEE
  * division and sqrt, float->int conversion truncates toward zero and
  * saturates, and exp() in render.comp is the function gso_exp() below
  * (GLSL leaves exp() precision to the driver: 3+2|x| ULP; gso_exp is < 3 ULP).
