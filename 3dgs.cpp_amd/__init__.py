@@ -7,3 +7,4 @@ valid Python identifier; load it with __graft_entry__.load_package() (module nam
 from . import synth  # noqa: F401
 from .binding import *  # noqa: F401,F403
 from . import binding  # noqa: F401
+from . import dist  # noqa: F401

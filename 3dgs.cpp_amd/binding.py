@@ -28,7 +28,7 @@ STAGES = dict(tiles=(0, np.uint32), depth=(1, np.float32), radius=(2, np.float32
               ranges=(13, np.uint32))
 
 # every symbol include/gs3d_hip.h declares
-SYMBOLS = ["gs_last_error", "gs_device_count", "gs_scene_load_ply", "gs_scene_from_records",
+SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_records", "gs_scene_load_ply", "gs_scene_from_records",
            "gs_scene_from_vertices", "gs_scene_from_device_blob", "gs_scene_blob_floats", "gs_scene_blob",
            "gs_scene_num_vertices", "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
@@ -105,6 +105,23 @@ def make_camera(position=(0, 0, 0), rotation=(1, 0, 0, 0), fov=45.0, near=0.1, f
 def camera_uniforms(cam, width, height):
     out = np.zeros(1, UNIFORMS_DT)
     _check(lib().gs_camera_uniforms(_p(cam), C.c_uint32(width), C.c_uint32(height), _p(out)))
+    return out
+
+
+def activate_records(records):
+    """GSScene::load's record conversion on the host (no GPU needed): (n, 62) -> (n, 60)."""
+    records = np.ascontiguousarray(records, np.float32).reshape(-1, RECORD_FLOATS)
+    out = np.zeros((len(records), VERTEX_FLOATS), np.float32)
+    _check(lib().gs_activate_records(_p(records), C.c_uint64(len(records)), _p(out)))
+    return out
+
+
+def read_ply(path):
+    """loadPlyHeader + payload (host only): raw (n, 62) records."""
+    n = C.c_uint64()
+    _check(lib().gs_read_ply(os.fsencode(path), None, C.c_uint64(0), C.byref(n)))
+    out = np.zeros((n.value, RECORD_FLOATS), np.float32)
+    _check(lib().gs_read_ply(os.fsencode(path), _p(out), C.c_uint64(n.value), C.byref(n)))
     return out
 
 

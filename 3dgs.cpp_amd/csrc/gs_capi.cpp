@@ -486,6 +486,27 @@ int gs_device_count(int* count) {
     });
 }
 
+int gs_activate_records(const float* records, uint64_t n, float* vertices) {
+    return guarded([&] {
+        if ((!records || !vertices) && n) throw Error(GS_ERR_INVALID, "null argument");
+        for (uint64_t i = 0; i < n; ++i)
+            gs::host::activate_record(records + i * gs::host::kRecordFloats, vertices + i * gs::host::kVertexFloats);
+    });
+}
+
+int gs_read_ply(const char* path, float* records, uint64_t capacity, uint64_t* n_out) {
+    return guarded([&] {
+        if (!path || !n_out) throw Error(GS_ERR_INVALID, "null argument");
+        uint64_t n = 0;
+        std::vector<float> rec = read_ply(path, &n);
+        *n_out = n;
+        if (records) {
+            if (capacity < n) throw Error(GS_ERR_INVALID, "record buffer too small");
+            std::memcpy(records, rec.data(), rec.size() * sizeof(float));
+        }
+    });
+}
+
 int gs_scene_load_ply(const char* path, int device, gs_scene** out) {
     return guarded([&] {
         if (!path || !out) throw Error(GS_ERR_INVALID, "null argument");

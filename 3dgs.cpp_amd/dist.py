@@ -1,0 +1,57 @@
+"""Multi-GPU plumbing: replicate the scene, shard camera poses.
+
+The path shards by frame: the scene is read-only, every pose is an independent unit, so there is no
+per-frame collective.  The only exchange is one broadcast of the packed SoA scene blob (59 floats per
+Gaussian) from rank 0 at load time -- torch.distributed backend "nccl" (RCCL over xGMI) on GPUs, "gloo"
+in the CPU tests.  Pure layout / bookkeeping; no arithmetic of the hot path lives here.
+"""
+import math
+
+import numpy as np
+
+BLOB_PLANES = 59  # pos 3, scale 3, rot 4, opacity 1, sh 48 (gs_kernels.h ScenePlane)
+
+
+def pack_blob(vertices):
+    """(n, 60) activated GSScene::Vertex rows -> packed SoA blob (59*n floats), plane-major."""
+    v = np.ascontiguousarray(vertices).view(np.float32).reshape(-1, 60)
+    n = len(v)
+    blob = np.empty((BLOB_PLANES, n), np.float32)
+    blob[0:3] = v[:, 0:3].T      # position xyz (w == 1 is implicit)
+    blob[3:6] = v[:, 4:7].T      # exp(scale)
+    blob[6:10] = v[:, 8:12].T    # rotation w x y z
+    blob[10] = v[:, 7]           # sigmoid(opacity)
+    blob[11:59] = v[:, 12:60].T  # 16 RGB triples
+    return blob.reshape(-1)
+
+
+def unpack_blob(blob, n):
+    """Inverse of pack_blob -> (n, 60) float32."""
+    b = np.asarray(blob, np.float32).reshape(BLOB_PLANES, n)
+    v = np.zeros((n, 60), np.float32)
+    v[:, 0:3] = b[0:3].T
+    v[:, 3] = 1.0
+    v[:, 4:7] = b[3:6].T
+    v[:, 7] = b[10]
+    v[:, 8:12] = b[6:10].T
+    v[:, 12:60] = b[11:59].T
+    return v
+
+
+def broadcast_blob(blob_tensor, src=0):
+    """One collective per scene: rank `src` -> everyone.  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(blob_tensor, src=src)
+    return blob_tensor
+
+
+def pose_quaternion(k, step_deg=5.0):
+    """Pose k of BASELINE config D: the default camera yawed by k * 5 degrees about world y (w, x, y, z)."""
+    a = math.radians(step_deg * k) / 2.0
+    return (math.cos(a), 0.0, math.sin(a), 0.0)
+
+
+def poses_for_rank(num_poses, rank, world):
+    """Pose i goes to rank i mod world."""
+    return [i for i in range(num_poses) if i % world == rank]

@@ -47,12 +47,6 @@ def algorithmic_bytes(n, v, d, t, p):
     }
 
 
-def yaw_quat(deg):
-    """Rotation about the world y axis (w, x, y, z)."""
-    a = math.radians(deg) / 2.0
-    return (math.cos(a), 0.0, math.sin(a), 0.0)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,14 +92,13 @@ def main():
         assert rc == 0
         scene0.close()
         del rec
-    if world > 1:
-        dist.broadcast(blob, src=0)
+    pkg.dist.broadcast_blob(blob, src=0)  # RCCL over xGMI; no-op at world == 1
     torch.cuda.synchronize()
     scene = pkg.Scene.from_device_blob(blob.data_ptr(), n, device=local_rank, keepalive=blob)
     rend = pkg.Renderer(scene)
     rend.set_frames_in_flight(args.frames_in_flight)
 
-    cam = pkg.make_camera(rotation=yaw_quat(5.0 * rank))  # pose k = default camera yawed k*5 deg
+    cam = pkg.make_camera(rotation=pkg.dist.pose_quaternion(rank))  # pose k = default camera yawed k*5 deg
     u = pkg.camera_uniforms(cam, w, h)
     out = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
     out8 = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if args.bgra8 else None

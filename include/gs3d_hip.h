@@ -102,6 +102,14 @@ int gs_device_count(int* count);
  * run the cov3D precompute (GSScene.cpp:157-184). */
 int gs_scene_load_ply(const char* path, int device, gs_scene** out);
 
+/* Host-only halves of GSScene::load, usable without a GPU:
+ *   gs_read_ply: loadPlyHeader + payload read (GSScene.cpp:99-149, :36-41); records may be NULL to
+ *                query *n_out first; capacity in records.
+ *   gs_activate_records: the per-record conversion (GSScene.cpp:42-55): exp(scale), sigmoid(opacity),
+ *                normalize(rot), planar->interleaved SH; n x 62 floats -> n x 60 floats (GSScene::Vertex). */
+int gs_read_ply(const char* path, float* records, uint64_t capacity, uint64_t* n_out);
+int gs_activate_records(const float* records, uint64_t n, float* vertices);
+
 /* Same, from n PLY-domain records (62 floats each, GSScene.cpp:17-24) in host memory. */
 int gs_scene_from_records(const float* records, uint64_t n, int device, gs_scene** out);
 

@@ -1,0 +1,115 @@
+"""CPU-side checks of the product library: it loads, exports the whole C ABI, its host arithmetic
+(camera uniforms, PLY ingest + activation) equals the oracle's bit for bit, and it refuses to run the
+GPU path without a GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "gs3d_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.binding.lib()
+    declared = header_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/gs3d_hip.h but not exported"
+    assert sorted(pkg.binding.SYMBOLS) == declared
+
+
+def test_struct_layouts(pkg):
+    assert pkg.binding.UNIFORMS_DT.itemsize == 160  # std140 block, Renderer.h:21-29
+    assert pkg.binding.CAMERA_DT.itemsize == 40
+    assert ctypes.sizeof(pkg.binding.FrameStats) == 64
+
+
+def test_camera_uniforms_match_oracle_bitwise(pkg, oracle):
+    rng = np.random.default_rng(0)
+    for i in range(200):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        pos = rng.uniform(-3, 3, size=3)
+        w, h = int(rng.integers(1, 4000)), int(rng.integers(1, 2200))
+        fov = float(rng.uniform(10, 120))
+        a = pkg.camera_uniforms(pkg.make_camera(pos, q, fov, 0.1, 1000.0), w, h)
+        b = oracle.camera_uniforms(oracle.default_camera(pos, q, fov, 0.1, 1000.0), w, h)
+        assert a.tobytes() == b.tobytes(), i
+
+
+def test_camera_uniforms_rejects_empty_framebuffer(pkg):
+    with pytest.raises(pkg.GsError) as e:
+        pkg.camera_uniforms(pkg.make_camera(), 0, 10)
+    assert e.value.code == -1
+
+
+def test_activation_matches_oracle_bitwise(pkg, oracle):
+    rec = pkg.synth.synth_records(5000, seed=4, kind="S", n_total=1_000_000)
+    a = pkg.activate_records(rec)
+    b = oracle.activate_records(rec).view(np.float32).reshape(-1, 60)
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_ply_roundtrip_and_errors(pkg, oracle, tmp_path):
+    rec = pkg.synth.synth_records(777, seed=9, kind="A")
+    path = str(tmp_path / "scene.ply")
+    pkg.synth.write_ply(path, rec)
+    np.testing.assert_array_equal(pkg.read_ply(path), rec)                 # product reader
+    np.testing.assert_array_equal(pkg.synth.read_ply_records(path), rec)   # python helper
+    ov = oracle.load_ply(path).view(np.float32).reshape(-1, 60)            # oracle reader + activation
+    np.testing.assert_array_equal(pkg.activate_records(pkg.read_ply(path)).view(np.uint32), ov.view(np.uint32))
+    # GSScene.h:29 "File does not exist: ..."
+    with pytest.raises(pkg.GsError) as e:
+        pkg.read_ply(str(tmp_path / "missing.ply"))
+    assert e.value.code == -2 and "File does not exist" in str(e.value)
+    # GSScene.cpp:147 "Could not find end of header"
+    bad = tmp_path / "bad.ply"
+    bad.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 3\n")
+    with pytest.raises(pkg.GsError) as e:
+        pkg.read_ply(str(bad))
+    assert "end of header" in str(e.value)
+    # truncated payload
+    trunc = tmp_path / "trunc.ply"
+    trunc.write_bytes(open(path, "rb").read()[:-100])
+    with pytest.raises(pkg.GsError):
+        pkg.read_ply(str(trunc))
+    # zero vertices
+    empty = str(tmp_path / "empty.ply")
+    pkg.synth.write_ply(empty, np.zeros((0, 62), np.float32))
+    assert pkg.read_ply(empty).shape == (0, 62)
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a GPU the product must fail loudly (GS_ERR_DEVICE), never compute on the host."""
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.GsError) as e:
+        pkg.Scene.from_records(pkg.synth.synth_records(8))
+    assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_references_the_oracle():
+    """oracle/ is test infrastructure: nothing under 3dgs.cpp_amd/ or include/ may mention it."""
+    for base in ("3dgs.cpp_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".so", ".pyc")):
+                    continue
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "gs_oracle" not in text and "gso_" not in text and "oracle/" not in text, os.path.join(dirpath, f)
+
+
+def test_synth_scene_is_deterministic_and_sliceable(pkg):
+    a = pkg.synth.synth_records(1000, seed=3, kind="S", n_total=4000)
+    b = pkg.synth.synth_records(400, seed=3, kind="S", n_total=4000, start=300)
+    np.testing.assert_array_equal(a[300:700], b)
+    assert not a[:, 3:6].any()  # normals are zero (GSScene.cpp:56-58)
+    assert abs(float(a[:, 55:58].mean()) - (-4.5 - np.log(4000 / 1e6) / 3)) < 0.05
