@@ -1,0 +1,86 @@
+"""The reference's own consumers against the new library, on the GPU:
+
+* viewer_ref -- /root/reference/apps/viewer/main.cpp compiled UNCHANGED (csrc/Makefile) and run headless;
+* embedded_host_test -- initialize()/draw()/logMovement()/logTranslation()/stop(), the Apple host's usage.
+
+Both dump B8G8R8A8 frames; they must equal the oracle's image for the camera the reference's input rules
+(Renderer.cpp:33-83, Renderer.h:47-49) produce."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "3dgs.cpp_amd")
+
+
+def read_ppm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = map(int, f.readline().split())
+        assert f.readline().strip() == b"255"
+        return np.frombuffer(f.read(), np.uint8).reshape(h, w, 3)
+
+
+def oracle_rgb8(oracle, verts, cam, w, h):
+    u = oracle.camera_uniforms(cam, w, h)
+    img, _ = oracle.render_frame(verts, oracle.cov3d(verts), u)
+    return oracle.pack_bgra8(img)[..., [2, 1, 0]]
+
+
+def qmul(p, q):
+    return np.array([p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3],
+                     p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2],
+                     p[0] * q[2] + p[2] * q[0] + p[3] * q[1] - p[1] * q[3],
+                     p[0] * q[3] + p[3] * q[0] + p[1] * q[2] - p[2] * q[1]])
+
+
+def axis_angle(angle, axis):
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    return np.concatenate([[math.cos(angle / 2)], a * math.sin(angle / 2)])
+
+
+def test_unchanged_reference_viewer_headless(pkg, oracle, gpu, tmp_path):
+    exe = os.path.join(PKG, "viewer_ref")
+    if not os.path.exists(exe):
+        pytest.skip("viewer_ref was not built (the reference tree was not mounted at build time)")
+    rec = pkg.synth.synth_records(6000, seed=12, kind="A")
+    ply = str(tmp_path / "scene.ply")
+    pkg.synth.write_ply(ply, rec)
+    w, h = 320, 208
+    env = dict(os.environ, GS_FRAMES="2", GS_DUMP_DIR=str(tmp_path))
+    out = subprocess.run([exe, "--no-gui", "--width", str(w), "--height", str(h), ply], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    frames = sorted(p for p in os.listdir(tmp_path) if p.endswith(".ppm"))
+    assert frames == ["frame_00000.ppm", "frame_00001.ppm"], out.stderr + out.stdout
+    ref = oracle_rgb8(oracle, oracle.activate_records(rec), oracle.default_camera(), w, h)
+    for f in frames:
+        np.testing.assert_array_equal(read_ppm(tmp_path / f), ref)
+
+
+def test_embedded_host_mode(pkg, oracle, gpu, tmp_path):
+    exe = os.path.join(PKG, "embedded_host_test")
+    rec = pkg.synth.synth_records(5000, seed=13, kind="A")
+    ply = str(tmp_path / "scene.ply")
+    pkg.synth.write_ply(ply, rec)
+    w, h = 256, 160
+    out = subprocess.run([exe, ply, str(w), str(h)], env=dict(os.environ, GS_DUMP_DIR=str(tmp_path)),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    verts = oracle.activate_records(rec)
+    # frame 0: default camera; frame 1: camera.translate with identity rotation
+    cams = [oracle.default_camera(), oracle.default_camera(position=(0.25, -0.5, 1.0))]
+    for k, cam in enumerate(cams):
+        np.testing.assert_array_equal(read_ppm(tmp_path / f"frame_{k:05d}.ppm"),
+                                      oracle_rgb8(oracle, verts, cam, w, h))
+    # frame 2: yaw 40*0.005 rad about (0,-1,0) then pitch -20*0.005 about (-1,0,0) (Renderer.cpp:46-51).
+    # float32 sin/cos in C++ vs float64 here move a few edge pixels: compare with a tolerance.
+    q = qmul(qmul(np.array([1.0, 0, 0, 0]), axis_angle(40 * 0.005, (0, -1, 0))), axis_angle(-20 * 0.005, (-1, 0, 0)))
+    got = read_ppm(tmp_path / "frame_00002.ppm").astype(int)
+    ref = oracle_rgb8(oracle, verts, oracle.default_camera(position=(0.25, -0.5, 1.0), rotation=tuple(q)), w, h).astype(int)
+    assert np.mean(np.abs(got - ref) > 1) < 0.02
+    assert np.abs(got - read_ppm(tmp_path / "frame_00001.ppm").astype(int)).max() > 10  # the pan moved the view
