@@ -175,6 +175,59 @@ std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
 // ------------------------------------------------------------------------------------------
 // gs_renderer
 // ------------------------------------------------------------------------------------------
+// One complete set of per-frame device buffers + the stream its passes run on.  Frames alternate between
+// sets, so with >= 2 sets the small launch-bound passes of frame i+1 (depth order, scans) overlap the
+// VALU-bound blend of frame i on the same GPU.
+struct FrameBuffers {
+    hipStream_t stream = nullptr;
+    // per-Gaussian attributes
+    DevBuf<uint32_t> tiles;
+    DevBuf<float> depth, radius, bch;
+    DevBuf<ushort4> aabb;
+    DevBuf<float4> conic_op, uv_rg;
+    // depth sort
+    DevBuf<uint32_t> dkeys[2], dvals[2], tiles_sorted, offsets;
+    DevBuf<uint32_t> block_hist, digit_total, scan_partial;
+    // instances
+    DevBuf<uint32_t> ikeys[2], ivals[2];
+    DevBuf<uint32_t> ranges;
+    DevBuf<gs::Counters> counters;
+    DevBuf<uint32_t> tap_tile, tap_gid;
+    bool ready = false;
+
+    void init(size_t n, uint32_t capacity) {
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        tiles.alloc(n);
+        depth.alloc(n);
+        radius.alloc(n);
+        bch.alloc(n);
+        aabb.alloc(n);
+        conic_op.alloc(n);
+        uv_rg.alloc(n);
+        for (int k = 0; k < 2; ++k) {
+            dkeys[k].alloc(n);
+            dvals[k].alloc(n);
+        }
+        tiles_sorted.alloc(n);
+        offsets.alloc(n);
+        block_hist.alloc(256 * static_cast<size_t>(gs::kSortMaxBlocks));
+        digit_total.alloc(256);
+        scan_partial.alloc(gs::kScanBlocks);
+        counters.alloc(1);
+        set_capacity(capacity);
+        ready = true;
+    }
+    void set_capacity(uint32_t cap) {
+        for (int k = 0; k < 2; ++k) {
+            ikeys[k].alloc(cap);
+            ivals[k].alloc(cap);
+        }
+    }
+    ~FrameBuffers() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
 struct FrameSlot {
     gs_uniforms u{};
     float* rgba = nullptr;
@@ -189,24 +242,13 @@ struct gs_renderer {
     static constexpr int kMaxInFlight = 4;
 
     gs_scene* scene = nullptr;
-    hipStream_t stream = nullptr;
     bool timing = true;
     bool keep_taps = false;  // debug: preserve the pre-sort instance arrays for gs_debug_download
-    DevBuf<uint32_t> tap_tile, tap_gid;
 
-    // per-Gaussian attributes
-    DevBuf<uint32_t> tiles;
-    DevBuf<float> depth, radius, bch;
-    DevBuf<ushort4> aabb;
-    DevBuf<float4> conic_op, uv_rg;
-    // depth sort
-    DevBuf<uint32_t> dkeys[2], dvals[2], tiles_sorted, offsets;
-    DevBuf<uint32_t> block_hist, digit_total, scan_partial;
-    // instances
+    FrameBuffers sets[kMaxInFlight];
+    int num_sets = 1;
     uint32_t capacity = 0;
-    DevBuf<uint32_t> ikeys[2], ivals[2];
-    DevBuf<uint32_t> ranges;
-    DevBuf<gs::Counters> counters;
+    FrameBuffers* last_set = nullptr;  // buffers of the most recently enqueued frame (stage taps)
 
     // frames in flight: a ring of descriptors, all enqueued on `stream` (so device buffers are
     // reused in stream order); the host only waits when the ring is full or on gs_synchronize.
@@ -235,51 +277,47 @@ struct gs_renderer {
             if (sl.done) (void)hipEventDestroy(sl.done);
             if (sl.h_counters) (void)hipHostFree(sl.h_counters);
         }
-        if (stream) (void)hipStreamDestroy(stream);
     }
 
     void set_capacity(uint32_t cap) {
         capacity = cap;
-        for (int k = 0; k < 2; ++k) {
-            ikeys[k].alloc(cap);
-            ivals[k].alloc(cap);
-        }
+        for (auto& fb : sets)
+            if (fb.ready) fb.set_capacity(cap);
     }
 
     void init() {
         HIP_CHECK(hipSetDevice(scene->device));
-        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto& sl : slots) {
             for (auto& e : sl.ev) HIP_CHECK(hipEventCreate(&e));
             HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(gs::Counters), hipHostMallocDefault));
             *sl.h_counters = gs::Counters{};
         }
-        const size_t n = scene->n;
-        tiles.alloc(n);
-        depth.alloc(n);
-        radius.alloc(n);
-        bch.alloc(n);
-        aabb.alloc(n);
-        conic_op.alloc(n);
-        uv_rg.alloc(n);
-        for (int k = 0; k < 2; ++k) {
-            dkeys[k].alloc(n);
-            dvals[k].alloc(n);
-        }
-        tiles_sorted.alloc(n);
-        offsets.alloc(n);
-        block_hist.alloc(256 * static_cast<size_t>(gs::kSortMaxBlocks));
-        digit_total.alloc(256);
-        scan_partial.alloc(gs::kScanBlocks);
-        counters.alloc(1);
-        const uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(n));
-        set_capacity(static_cast<uint32_t>(std::min<uint64_t>(want, 0xFFFFF000ull)));
+        const uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(scene->n));
+        capacity = static_cast<uint32_t>(std::min<uint64_t>(want, 0xFFFFF000ull));
+        sets[0].init(scene->n, capacity);
+    }
+
+    void set_num_sets(int k) {
+        for (int i = 0; i < k; ++i)
+            if (!sets[i].ready) sets[i].init(scene->n, capacity);
+        num_sets = k;
     }
 
     void enqueue(const gs_uniforms& u, float* d_rgba, uint8_t* d_bgra) {
         HIP_CHECK(hipSetDevice(scene->device));
         FrameSlot& sl = slots[frames_enqueued % kMaxInFlight];
+        FrameBuffers& fb = sets[frames_enqueued % num_sets];
+        hipStream_t stream = fb.stream;
+        auto &tiles = fb.tiles, &tiles_sorted = fb.tiles_sorted, &offsets = fb.offsets, &block_hist = fb.block_hist,
+             &digit_total = fb.digit_total, &scan_partial = fb.scan_partial, &ranges = fb.ranges,
+             &tap_tile = fb.tap_tile, &tap_gid = fb.tap_gid;
+        auto &depth = fb.depth, &radius = fb.radius, &bch = fb.bch;
+        auto &aabb = fb.aabb;
+        auto &conic_op = fb.conic_op, &uv_rg = fb.uv_rg;
+        auto &dkeys = fb.dkeys, &dvals = fb.dvals, &ikeys = fb.ikeys, &ivals = fb.ivals;
+        auto &counters = fb.counters;
+        last_set = &fb;
         hipEvent_t* ev = sl.ev;
         const uint32_t n = static_cast<uint32_t>(scene->n);
         const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
@@ -410,7 +448,8 @@ struct gs_renderer {
         FrameSlot& sl = oldest();
         HIP_CHECK(hipEventSynchronize(sl.done));
         if (sl.h_counters->overflow) {
-            HIP_CHECK(hipStreamSynchronize(stream));
+            for (auto& fb : sets)
+                if (fb.ready) HIP_CHECK(hipStreamSynchronize(fb.stream));
             struct Redo {
                 gs_uniforms u;
                 float* rgba;
@@ -612,7 +651,9 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
 }
 
 void gs_renderer_destroy(gs_renderer* r) {
-    if (r && r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r)
+        for (auto& fb : r->sets)
+            if (fb.ready) (void)hipStreamSynchronize(fb.stream);
     delete r;
 }
 
@@ -680,6 +721,7 @@ int gs_set_frames_in_flight(gs_renderer* r, int frames) {
         if (frames < 1 || frames > gs_renderer::kMaxInFlight) throw Error(GS_ERR_INVALID, "frames in flight must be 1..4");
         r->drain();
         r->in_flight_limit = frames;
+        r->set_num_sets(frames);
     });
 }
 
@@ -724,15 +766,15 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
         const void* src = nullptr;
         uint64_t size = 0;
         switch (stage) {
-            case GS_STAGE_TILES: src = r->tiles.p; size = n * 4; break;
-            case GS_STAGE_DEPTH: src = r->depth.p; size = n * 4; break;
-            case GS_STAGE_RADIUS: src = r->radius.p; size = n * 4; break;
-            case GS_STAGE_AABB: src = r->aabb.p; size = n * 8; break;
-            case GS_STAGE_CONIC_OPACITY: src = r->conic_op.p; size = n * 16; break;
-            case GS_STAGE_UV_RG: src = r->uv_rg.p; size = n * 16; break;
-            case GS_STAGE_B: src = r->bch.p; size = n * 4; break;
+            case GS_STAGE_TILES: src = r->last_set->tiles.p; size = n * 4; break;
+            case GS_STAGE_DEPTH: src = r->last_set->depth.p; size = n * 4; break;
+            case GS_STAGE_RADIUS: src = r->last_set->radius.p; size = n * 4; break;
+            case GS_STAGE_AABB: src = r->last_set->aabb.p; size = n * 8; break;
+            case GS_STAGE_CONIC_OPACITY: src = r->last_set->conic_op.p; size = n * 16; break;
+            case GS_STAGE_UV_RG: src = r->last_set->uv_rg.p; size = n * 16; break;
+            case GS_STAGE_B: src = r->last_set->bch.p; size = n * 4; break;
             case GS_STAGE_DEPTH_ORDER: src = r->depth_order; size = v * 4; break;
-            case GS_STAGE_OFFSETS: src = r->offsets.p; size = v * 4; break;
+            case GS_STAGE_OFFSETS: src = r->last_set->offsets.p; size = v * 4; break;
             case GS_STAGE_INSTANCE_TILE:
             case GS_STAGE_INSTANCE_GID:
                 if (!r->keep_taps) throw Error(GS_ERR_INVALID, "enable gs_set_debug_taps before rendering to read pre-sort instances");
@@ -741,7 +783,7 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
                 break;
             case GS_STAGE_SORTED_TILE: src = r->sorted_tile; size = d * 4; break;
             case GS_STAGE_SORTED_GID: src = r->sorted_gid; size = d * 4; break;
-            case GS_STAGE_RANGES: src = r->ranges.p; size = r->num_tiles * 8; break;
+            case GS_STAGE_RANGES: src = r->last_set->ranges.p; size = r->num_tiles * 8; break;
             default: throw Error(GS_ERR_INVALID, "unknown stage");
         }
         if (bytes < size) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
@@ -749,6 +791,6 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
     });
 }
 
-void* gs_renderer_stream(gs_renderer* r) { return r ? r->stream : nullptr; }
+void* gs_renderer_stream(gs_renderer* r) { return r ? r->sets[0].stream : nullptr; }
 
 }  // extern "C"

@@ -100,9 +100,14 @@ def main():
 
     cam = pkg.make_camera(rotation=pkg.dist.pose_quaternion(rank))  # pose k = default camera yawed k*5 deg
     u = pkg.camera_uniforms(cam, w, h)
-    out = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
-    out8 = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if args.bgra8 else None
-    p8 = out8.data_ptr() if out8 is not None else 0
+    # one output image per frame in flight (frames on different streams must not share a target)
+    fif = args.frames_in_flight
+    outs = [torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(fif)]
+    outs8 = [torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if args.bgra8 else None for _ in range(fif)]
+
+    def submit(i):
+        o8 = outs8[i % fif]
+        rend.render(u, outs[i % fif].data_ptr(), o8.data_ptr() if o8 is not None else 0)
 
     def sync_all():
         rend.synchronize()
@@ -110,14 +115,14 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        rend.render(u, out.data_ptr(), p8)
+    for i in range(args.warmup):
+        submit(i)
     sync_all()
     rend.timing_totals(reset=True)
 
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rend.render(u, out.data_ptr(), p8)
+    for i in range(args.steps):
+        submit(i)
     rend.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

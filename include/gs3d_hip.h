@@ -158,8 +158,10 @@ int gs_synchronize(gs_renderer* r);
 /* Enable/disable the six hipEvent spans (off: one total span only). */
 int gs_set_timing(gs_renderer* r, int enabled);
 /* Frames that may be queued on the stream before gs_render blocks (1..4, default 1 like
- * FRAMES_IN_FLIGHT, VulkanContext.h:6).  With k > 1 the host enqueues frame i+1 while frame i
- * runs; an overflowed frame and everything queued behind it are re-run after growing. */
+ * FRAMES_IN_FLIGHT, VulkanContext.h:6).  With k > 1 the renderer keeps k sets of per-frame buffers
+ * on k streams: the host enqueues frame i+1 while frame i runs, and the two frames' passes overlap
+ * on the GPU.  Frames that may be in flight together must be given distinct output buffers.  An
+ * overflowed frame and everything queued behind it are re-run after growing. */
 int gs_set_frames_in_flight(gs_renderer* r, int frames);
 /* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
  * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
