@@ -816,9 +816,9 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                                                  const float4* __restrict__ uv_rg, const float* __restrict__ bch,
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
                                                  float4* __restrict__ rgba, uchar4* __restrict__ bgra) {
-    __shared__ float4 s_co[4][WAVE];   // wave-private slabs: no cross-wave sharing, no barriers
-    __shared__ float4 s_uv[4][WAVE];
-    __shared__ float2 s_bp[4][WAVE];   // b, lower bound on power
+    // wave-private slabs (no cross-wave sharing, no barriers); one 48-byte record per entry so that a
+    // single scalar-derived address serves all three broadcast reads of the inner loop
+    __shared__ float4 s_rec[4][WAVE][4];  // {c00 c01 c11 o} {u v r g} {b, pmin, -, -} {pad}: 64-byte stride
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const uint32_t qx0 = blockIdx.x * kTile + (w & 1) * 8, qy0 = blockIdx.y * kTile + (w >> 1) * 8;
@@ -829,9 +829,11 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
 
     const uint2 range = ranges[blockIdx.x + blockIdx.y * tiles_x];
     float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    bool done = !inside;
+    // Pixel predicates live in 64-bit scalar masks (one bit per lane): combining them is scalar-unit work
+    // and testing "any lane" is one s_cmp, where bool-typed code would spend VALU instructions on it.
+    uint64_t alive = __builtin_amdgcn_ballot_w64(inside);  // pixels still accumulating
 
-    if (__ballot(!done) != 0 && range.x < range.y) {
+    if (alive != 0 && range.x < range.y) {
         // software pipeline over 64-entry chunks: ids two chunks ahead, records one chunk ahead
         BlendEntry nxt;
         nxt.co = make_float4(0, 0, 0, 0);
@@ -867,44 +869,44 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
             STAT_ADD(6, __popcll(__ballot(have)));
             STAT_ADD(1, __popcll(bm));
             if (bm == 0) continue;
-            s_co[w][lane] = cur.co;
-            s_uv[w][lane] = cur.uv;
-            s_bp[w][lane] = make_float2(cur.b, -lim);
+            s_rec[w][lane][0] = cur.co;
+            s_rec[w][lane][1] = cur.uv;
+            s_rec[w][lane][2] = make_float4(cur.b, -lim, 0.0f, 0.0f);
 
             while (bm) {
                 const int k = __ffsll((unsigned long long)bm) - 1;
                 bm &= bm - 1;
-                STAT_ADD(2, 1);                             // (entry, wave) pairs evaluated
-                STAT_ADD(3, __popcll(__ballot(!done)));     // lanes alive
-                const float4 co = s_co[w][k];
-                const float4 uv = s_uv[w][k];
-                const float2 bp = s_bp[w][k];
+                STAT_ADD(2, 1);                       // (entry, wave) pairs evaluated
+                STAT_ADD(3, __popcll(alive));         // lanes alive
+                const float4 co = s_rec[w][k][0];
+                const float4 uv = s_rec[w][k][1];
+                const float4 bp = s_rec[w][k][2];
                 const float dx = uv.x - fx;
                 const float dy = uv.y - fy;
                 // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
                 const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);        // FMA
                 const float power = __builtin_fmaf(-(co.y * dx), dy, -0.5f * s);      // FMA
-                const bool p1 = !done && !(power > 0.0f) && !(power < bp.y);
-                if (__ballot(p1) != 0) {
-                    STAT_ADD(4, 1);                         // pairs reaching exp
-                    STAT_ADD(5, __popcll(__ballot(p1)));    // lanes needing exp
+                const uint64_t m1 = alive & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+                                    __builtin_amdgcn_ballot_w64(!(power < bp.y));
+                if (m1 != 0) {
+                    STAT_ADD(4, 1);                   // pairs reaching exp
+                    STAT_ADD(5, __popcll(m1));        // lanes needing exp
                     const float alpha = fminf(0.99f, co.w * gs_exp_blend(power));  // :77
-                    const bool p2 = p1 && !(alpha < 1.0f / 255.0f);
+                    const uint64_t m2 = m1 & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
                     const float test_T = T * (1 - alpha);
-                    const bool kill = p2 && (test_T < 0.0001f);  // :82-85
-                    const bool upd = p2 && !kill;
-                    const float n0 = __builtin_fmaf(uv.z * alpha, T, c0);  // :87  FMA
-                    const float n1 = __builtin_fmaf(uv.w * alpha, T, c1);
-                    const float n2 = __builtin_fmaf(bp.x * alpha, T, c2);
-                    c0 = upd ? n0 : c0;
-                    c1 = upd ? n1 : c1;
-                    c2 = upd ? n2 : c2;
+                    const uint64_t mk = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);  // :82-85 break
+                    const bool upd = __builtin_amdgcn_inverse_ballot_w64(m2 & ~mk);
+                    // lanes that do not take this entry add rgb * 0 * T: exactly nothing
+                    const float a_eff = upd ? alpha : 0.0f;
+                    c0 = __builtin_fmaf(uv.z * a_eff, T, c0);  // :87  FMA
+                    c1 = __builtin_fmaf(uv.w * a_eff, T, c1);
+                    c2 = __builtin_fmaf(bp.x * a_eff, T, c2);
                     T = upd ? test_T : T;
-                    done = done || kill;
-                    if (__ballot(!done) == 0) bm = 0;
+                    alive &= ~mk;
+                    if (alive == 0) bm = 0;
                 }
             }
-            if (__ballot(!done) == 0) break;
+            if (alive == 0) break;
         }
     }
     if (inside) {
