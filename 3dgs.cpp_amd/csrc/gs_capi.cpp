@@ -239,7 +239,7 @@ struct FrameSlot {
 };
 
 struct gs_renderer {
-    static constexpr int kMaxInFlight = 4;
+    static constexpr int kMaxInFlight = 8;
 
     gs_scene* scene = nullptr;
     bool timing = true;
@@ -718,7 +718,7 @@ int gs_set_debug_taps(gs_renderer* r, int enabled) {
 int gs_set_frames_in_flight(gs_renderer* r, int frames) {
     return guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "null argument");
-        if (frames < 1 || frames > gs_renderer::kMaxInFlight) throw Error(GS_ERR_INVALID, "frames in flight must be 1..4");
+        if (frames < 1 || frames > gs_renderer::kMaxInFlight) throw Error(GS_ERR_INVALID, "frames in flight must be 1..8");
         r->drain();
         r->in_flight_limit = frames;
         r->set_num_sets(frames);

@@ -157,7 +157,7 @@ int gs_render_host(gs_renderer* r, const gs_uniforms* u, float* h_rgba, uint8_t*
 int gs_synchronize(gs_renderer* r);
 /* Enable/disable the six hipEvent spans (off: one total span only). */
 int gs_set_timing(gs_renderer* r, int enabled);
-/* Frames that may be queued on the stream before gs_render blocks (1..4, default 1 like
+/* Frames that may be queued on the stream before gs_render blocks (1..8, default 1 like
  * FRAMES_IN_FLIGHT, VulkanContext.h:6).  With k > 1 the renderer keeps k sets of per-frame buffers
  * on k streams: the host enqueues frame i+1 while frame i runs, and the two frames' passes overlap
  * on the GPU.  Frames that may be in flight together must be given distinct output buffers.  An
