@@ -191,6 +191,7 @@ struct FrameBuffers {
     // instances
     DevBuf<uint32_t> ikeys[2], ivals[2];
     DevBuf<uint32_t> ranges;
+    DevBuf<uint32_t> sorted, chunk_hist, tile_total;  // hierarchical binning
     DevBuf<gs::Counters> counters;
     DevBuf<uint32_t> tap_tile, tap_gid;
     bool ready = false;
@@ -222,6 +223,7 @@ struct FrameBuffers {
             ikeys[k].alloc(cap);
             ivals[k].alloc(cap);
         }
+        sorted.alloc(cap);
     }
     ~FrameBuffers() {
         if (stream) (void)hipStreamDestroy(stream);
@@ -232,7 +234,7 @@ struct FrameSlot {
     gs_uniforms u{};
     float* rgba = nullptr;
     uint8_t* bgra = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[9] = {};
     hipEvent_t done = nullptr;
     gs::Counters* h_counters = nullptr;  // pinned
     bool timed = false;
@@ -244,6 +246,7 @@ struct gs_renderer {
     gs_scene* scene = nullptr;
     bool timing = true;
     bool keep_taps = false;  // debug: preserve the pre-sort instance arrays for gs_debug_download
+    bool use_binning = true; // GS_TILE_PATH=sort selects the instance-sort path (A/B measurements)
 
     FrameBuffers sets[kMaxInFlight];
     int num_sets = 1;
@@ -293,6 +296,7 @@ struct gs_renderer {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(gs::Counters), hipHostMallocDefault));
             *sl.h_counters = gs::Counters{};
         }
+        if (const char* e = std::getenv("GS_TILE_PATH")) use_binning = std::string(e) != "sort";
         const uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(scene->n));
         capacity = static_cast<uint32_t>(std::min<uint64_t>(want, 0xFFFFF000ull));
         sets[0].init(scene->n, capacity);
@@ -311,7 +315,8 @@ struct gs_renderer {
         hipStream_t stream = fb.stream;
         auto &tiles = fb.tiles, &tiles_sorted = fb.tiles_sorted, &offsets = fb.offsets, &block_hist = fb.block_hist,
              &digit_total = fb.digit_total, &scan_partial = fb.scan_partial, &ranges = fb.ranges,
-             &tap_tile = fb.tap_tile, &tap_gid = fb.tap_gid;
+             &tap_tile = fb.tap_tile, &tap_gid = fb.tap_gid, &sorted = fb.sorted, &chunk_hist = fb.chunk_hist,
+             &tile_total = fb.tile_total;
         auto &depth = fb.depth, &radius = fb.radius, &bch = fb.bch;
         auto &aabb = fb.aabb;
         auto &conic_op = fb.conic_op, &uv_rg = fb.uv_rg;
@@ -323,9 +328,18 @@ struct gs_renderer {
         const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
         if (tx > 65535 || ty > 65535) throw Error(GS_ERR_INVALID, "resolution too large (tile box is 16-bit)");
         const uint64_t nt = static_cast<uint64_t>(tx) * ty;
-        if (2 * nt > ranges.n) {  // resize: wait for queued frames that still use the old buffer
-            drain();
-            ranges.alloc(2 * nt);
+        // bins of S x S tiles, at most 256 of them
+        int bin_shift = 3;
+        while ((((tx - 1) >> bin_shift) + 1) * (((ty - 1) >> bin_shift) + 1) > 256) ++bin_shift;
+        const uint32_t bins_x = ((tx - 1) >> bin_shift) + 1, bins_y = ((ty - 1) >> bin_shift) + 1;
+        const uint32_t bin_tiles = 1u << (2 * bin_shift);
+        if (bin_tiles > 1024) throw Error(GS_ERR_INVALID, "resolution too large for the tile binning (max 8192 x 8192)");
+        const uint32_t max_chunks = capacity / 256 + 256;
+        if (2 * nt > ranges.n || static_cast<size_t>(max_chunks) * bin_tiles > chunk_hist.n) {
+            drain();  // resize: wait for queued frames that still use the old buffers
+            ranges.ensure(2 * nt);
+            tile_total.ensure(nt);
+            chunk_hist.ensure(static_cast<size_t>(max_chunks) * bin_tiles);
         }
         num_tiles = nt;
 
@@ -361,7 +375,12 @@ struct gs_renderer {
                 p.blocks = blocks;
                 p.first = pass == 0;
                 if (pass == 3) {
-                    p.gather_tiles = tiles.p;
+                    if (use_binning) {  // per Gaussian: how many bins its tile box touches
+                        p.gather_aabb = aabb.p;
+                        p.bin_shift = bin_shift;
+                    } else {
+                        p.gather_tiles = tiles.p;
+                    }
                     p.tiles_sorted = tiles_sorted.p;
                 }
                 gs::launch_radix_pass(p, stream);
@@ -372,58 +391,111 @@ struct gs_renderer {
         }
         if (timing) HIP_CHECK(hipEventRecord(ev[2], stream));
 
-        // ---- offsets = exclusive scan of tiles_overlap in depth order; D -> counters ----
-        gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, &cnt->visible, n, scan_partial.p, &cnt->instances, stream);
-        if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
-
-        // ---- duplicate ----
-        inst_tile = ikeys[0].p;
-        inst_gid = ivals[0].p;
-        gs::launch_duplicate(depth_order, offsets.p, tiles_sorted.p, aabb.p, &cnt->visible, n, tx, capacity,
-                             inst_tile, inst_gid, cnt, stream);
-        if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
-        if (keep_taps) {  // the tile sort ping-pongs over the duplicate output
-            tap_tile.ensure(capacity);
-            tap_gid.ensure(capacity);
-            HIP_CHECK(hipMemcpyAsync(tap_tile.p, inst_tile, capacity * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(tap_gid.p, inst_gid, capacity * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-            inst_tile = tap_tile.p;
-            inst_gid = tap_gid.p;
-        }
-
-        // ---- stable sort by tile id (instances are already in depth order) ----
-        {
-            int bits = 0;
-            while ((1ull << bits) < num_tiles) ++bits;
-            const int passes = (bits + 7) / 8;
-            const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (capacity + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
-            int src = 0;
-            for (int pass = 0; pass < passes; ++pass) {
+        if (use_binning) {
+            // ---- level 1: (bin, Gaussian) candidates in depth order, one stable pass by bin ----
+            gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, &cnt->visible, n, scan_partial.p, &cnt->bin_entries, stream);
+            if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
+            gs::launch_duplicate(depth_order, offsets.p, tiles_sorted.p, aabb.p, &cnt->visible, n, bins_x, bin_shift,
+                                 capacity, ikeys[0].p, ivals[0].p, cnt, stream);
+            if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
+            {
                 gs::RadixPass p{};
-                p.keys_in = ikeys[src].p;
-                p.vals_in = ivals[src].p;
-                p.keys_out = ikeys[src ^ 1].p;
-                p.vals_out = ivals[src ^ 1].p;
-                p.n_in = &cnt->instances;
+                p.keys_in = ikeys[0].p;
+                p.vals_in = ivals[0].p;
+                p.keys_out = ikeys[1].p;
+                p.vals_out = ivals[1].p;
+                p.n_in = &cnt->bin_entries;
                 p.n_static = capacity;
                 p.block_hist = block_hist.p;
                 p.digit_total = digit_total.p;
-                p.shift = pass * 8;
-                p.bits = std::min(8, bits - pass * 8);
-                p.blocks = blocks;
-                p.first = 0;
+                p.shift = 0;
+                p.bits = 8;
+                p.blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (capacity + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
                 gs::launch_radix_pass(p, stream);
-                src ^= 1;
             }
-            sorted_tile = ikeys[src].p;
-            sorted_gid = ivals[src].p;
-        }
-        if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
+            if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
+            // ---- level 2: per-tile counts -> ranges and D (tile_boundary), then the per-tile lists ----
+            gs::BinLaunch b{};
+            b.cand = ivals[1].p;
+            b.bin_count = digit_total.p;
+            b.aabb = aabb.p;
+            b.chunk_hist = chunk_hist.p;
+            b.tile_total = tile_total.p;
+            b.ranges = ranges.p;
+            b.sorted_gid = sorted.p;
+            b.counters = cnt;
+            b.capacity = capacity;
+            b.tiles_x = tx;
+            b.tiles_y = ty;
+            b.bins_x = bins_x;
+            b.bins = bins_x * bins_y;
+            b.shift = bin_shift;
+            b.max_chunks = max_chunks;
+            gs::launch_bin_ranges(b, stream);
+            if (timing) HIP_CHECK(hipEventRecord(ev[6], stream));
+            gs::launch_bin_fill(b, stream);
+            if (timing) HIP_CHECK(hipEventRecord(ev[8], stream));
+            sorted_gid = sorted.p;
+            sorted_tile = nullptr;
+            inst_tile = inst_gid = nullptr;
+        } else {
+            // ---- offsets = exclusive scan of tiles_overlap in depth order; D -> counters ----
+            gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, &cnt->visible, n, scan_partial.p, &cnt->bin_entries, stream);
+            if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
 
-        // ---- tile ranges (Renderer.cpp:633 fill + tile_boundary) ----
-        HIP_CHECK(hipMemsetAsync(ranges.p, 0, 2 * num_tiles * sizeof(uint32_t), stream));
-        gs::launch_tile_ranges(sorted_tile, &cnt->instances, capacity, ranges.p, stream);
-        if (timing) HIP_CHECK(hipEventRecord(ev[6], stream));
+            // ---- duplicate ----
+            inst_tile = ikeys[0].p;
+            inst_gid = ivals[0].p;
+            gs::launch_duplicate(depth_order, offsets.p, tiles_sorted.p, aabb.p, &cnt->visible, n, tx, 0, capacity,
+                                 inst_tile, inst_gid, cnt, stream);
+            HIP_CHECK(hipMemcpyAsync(&cnt->instances, &cnt->bin_entries, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
+            if (keep_taps) {  // the tile sort ping-pongs over the duplicate output
+                tap_tile.ensure(capacity);
+                tap_gid.ensure(capacity);
+                HIP_CHECK(hipMemcpyAsync(tap_tile.p, inst_tile, capacity * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+                HIP_CHECK(hipMemcpyAsync(tap_gid.p, inst_gid, capacity * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+                inst_tile = tap_tile.p;
+                inst_gid = tap_gid.p;
+            }
+
+            // ---- stable sort by tile id (instances are already in depth order) ----
+            {
+                int bits = 0;
+                while ((1ull << bits) < num_tiles) ++bits;
+                const int passes = (bits + 7) / 8;
+                const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (capacity + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
+                int src = 0;
+                for (int pass = 0; pass < passes; ++pass) {
+                    gs::RadixPass p{};
+                    p.keys_in = ikeys[src].p;
+                    p.vals_in = ivals[src].p;
+                    p.keys_out = ikeys[src ^ 1].p;
+                    p.vals_out = ivals[src ^ 1].p;
+                    p.n_in = &cnt->instances;
+                    p.n_static = capacity;
+                    p.block_hist = block_hist.p;
+                    p.digit_total = digit_total.p;
+                    p.shift = pass * 8;
+                    p.bits = std::min(8, bits - pass * 8);
+                    p.blocks = blocks;
+                    p.first = 0;
+                    gs::launch_radix_pass(p, stream);
+                    src ^= 1;
+                }
+                sorted_tile = ikeys[src].p;
+                sorted_gid = ivals[src].p;
+            }
+            if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
+
+            // ---- tile ranges (Renderer.cpp:633 fill + tile_boundary) ----
+            HIP_CHECK(hipMemsetAsync(ranges.p, 0, 2 * num_tiles * sizeof(uint32_t), stream));
+            gs::launch_tile_ranges(sorted_tile, &cnt->instances, capacity, ranges.p, stream);
+            if (timing) {
+                HIP_CHECK(hipEventRecord(ev[6], stream));
+                HIP_CHECK(hipEventRecord(ev[8], stream));
+            }
+        }
 
         // ---- blend ----
         gs::launch_blend(ranges.p, sorted_gid, av, u.width, u.height, d_rgba, d_bgra, stream);
@@ -485,11 +557,11 @@ struct gs_renderer {
         st.ms_total = span(0, 7);
         if (sl.timed) {
             st.ms_preprocess = span(0, 1);
-            st.ms_sort = span(1, 2) + span(4, 5);
+            st.ms_sort = span(1, 2) + span(4, 5) + span(6, 8);
             st.ms_prefix_sum = span(2, 3);
             st.ms_preprocess_sort = span(3, 4);
             st.ms_tile_boundary = span(5, 6);
-            st.ms_render = span(6, 7);
+            st.ms_render = span(8, 7);
         }
         st.retries = retries;
         last = st;
@@ -777,11 +849,24 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
             case GS_STAGE_OFFSETS: src = r->last_set->offsets.p; size = v * 4; break;
             case GS_STAGE_INSTANCE_TILE:
             case GS_STAGE_INSTANCE_GID:
+                if (r->use_binning) throw Error(GS_ERR_INVALID, "the binning path has no unsorted instance list (GS_TILE_PATH=sort has)");
                 if (!r->keep_taps) throw Error(GS_ERR_INVALID, "enable gs_set_debug_taps before rendering to read pre-sort instances");
                 src = stage == GS_STAGE_INSTANCE_TILE ? r->inst_tile : r->inst_gid;
                 size = d * 4;
                 break;
-            case GS_STAGE_SORTED_TILE: src = r->sorted_tile; size = d * 4; break;
+            case GS_STAGE_SORTED_TILE:
+                if (!r->sorted_tile) {  // binning path: the tile id of list position i follows from the ranges
+                    if (bytes < d * 4) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
+                    std::vector<uint32_t> rg(2 * r->num_tiles);
+                    if (!rg.empty()) HIP_CHECK(hipMemcpy(rg.data(), r->last_set->ranges.p, rg.size() * 4, hipMemcpyDeviceToHost));
+                    uint32_t* out = static_cast<uint32_t*>(dst);
+                    for (uint64_t t = 0; t < r->num_tiles; ++t)
+                        for (uint64_t i = rg[2 * t]; i < std::min<uint64_t>(rg[2 * t + 1], d); ++i) out[i] = static_cast<uint32_t>(t);
+                    return;
+                }
+                src = r->sorted_tile;
+                size = d * 4;
+                break;
             case GS_STAGE_SORTED_GID: src = r->sorted_gid; size = d * 4; break;
             case GS_STAGE_RANGES: src = r->last_set->ranges.p; size = r->num_tiles * 8; break;
             default: throw Error(GS_ERR_INVALID, "unknown stage");

@@ -38,7 +38,7 @@ struct Counters {
     uint32_t visible;    // V
     uint32_t instances;  // D (may exceed capacity: then `overflow` is set and nothing past capacity is written)
     uint32_t overflow;
-    uint32_t pad;
+    uint32_t bin_entries;  // E1: (bin, Gaussian) candidates of the level-1 binning
 };
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s);
@@ -65,6 +65,8 @@ struct RadixPass {
     int blocks;
     int first;
     const uint32_t* gather_tiles;  // last depth pass: also emit tiles[value] in sorted order ...
+    const ushort4* gather_aabb;    // ... or, when set, the number of (tile >> bin_shift) bins its box touches ...
+    int bin_shift;
     uint32_t* tiles_sorted;        // ... here (may be null)
 };
 void launch_radix_pass(const RadixPass& p, hipStream_t s);
@@ -77,8 +79,27 @@ void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n
 // tile ids (x outer, y inner) and g at off[j]...  Sets counters->overflow when D > capacity.
 void launch_duplicate(const uint32_t* order, const uint32_t* off, const uint32_t* tiles_sorted,
                       const ushort4* aabb, const uint32_t* n_visible, uint32_t n_bound, uint32_t tiles_x,
-                      uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,
+                      int shift, uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,
                       hipStream_t s);
+
+// Level 2 of the hierarchical binning (k_bin_count, k_bin_scan, k_tile_scan, k_bin_fill): expands the
+// bin-major candidate list into per-tile lists, the tile ranges and D.
+struct BinLaunch {
+    const uint32_t* cand;
+    const uint32_t* bin_count;  // [256]
+    const ushort4* aabb;
+    uint32_t* chunk_hist;       // [max_chunks][S*S]
+    uint32_t* tile_total;       // [T], zero-filled by the caller
+    uint32_t* ranges;           // [T][2]
+    uint32_t* sorted_gid;
+    Counters* counters;
+    uint32_t capacity;
+    uint32_t tiles_x, tiles_y, bins_x, bins;
+    int shift;
+    uint32_t max_chunks;
+};
+void launch_bin_ranges(const BinLaunch& b, hipStream_t s);  // k_bin_count, k_bin_scan, k_tile_scan
+void launch_bin_fill(const BinLaunch& b, hipStream_t s);    // k_bin_fill
 
 // tile_boundary.comp counterpart (ranges must be zero-filled before).
 void launch_tile_ranges(const uint32_t* sorted_tile, const uint32_t* n, uint32_t capacity, uint32_t* ranges,

@@ -355,7 +355,9 @@ struct RadixArgs {
     uint32_t* block_hist;
     uint32_t* digit_total;
     const uint32_t* gather_tiles;
+    const ushort4* gather_aabb;
     uint32_t* tiles_sorted;
+    int bin_shift;
     int shift;
     uint32_t mask;
     int blocks;
@@ -520,7 +522,16 @@ __global__ __launch_bounds__(BLOCK) void k_radix_scatter(RadixArgs a) {
                 const uint32_t dst = s_base[d] + (slot - s_texcl[d]);
                 a.keys_out[dst] = k2;
                 a.vals_out[dst] = v2;
-                if (a.tiles_sorted) a.tiles_sorted[dst] = a.gather_tiles[v2];
+                if (a.tiles_sorted) {
+                    if (a.gather_aabb) {  // number of S x S-tile bins the Gaussian's tile box touches
+                        const ushort4 bx = a.gather_aabb[v2];
+                        const uint32_t nx = ((bx.z - 1u) >> a.bin_shift) - (bx.x >> a.bin_shift) + 1u;
+                        const uint32_t ny = ((bx.w - 1u) >> a.bin_shift) - (bx.y >> a.bin_shift) + 1u;
+                        a.tiles_sorted[dst] = nx * ny;
+                    } else {
+                        a.tiles_sorted[dst] = a.gather_tiles[v2];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -542,6 +553,8 @@ void launch_radix_pass(const RadixPass& p, hipStream_t s) {
     a.block_hist = p.block_hist;
     a.digit_total = p.digit_total;
     a.gather_tiles = p.gather_tiles;
+    a.gather_aabb = p.gather_aabb;
+    a.bin_shift = p.bin_shift;
     a.tiles_sorted = p.tiles_sorted;
     a.shift = p.shift;
     a.mask = (1u << p.bits) - 1u;
@@ -641,14 +654,14 @@ __global__ __launch_bounds__(BLOCK) void k_duplicate(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ tiles_sorted,
                                                      const ushort4* __restrict__ aabb, const uint32_t* n_visible,
-                                                     uint32_t n_bound, uint32_t tiles_x, uint32_t capacity,
+                                                     uint32_t n_bound, uint32_t tiles_x, int shift, uint32_t capacity,
                                                      uint32_t* __restrict__ inst_tile,
                                                      uint32_t* __restrict__ inst_gid, Counters* counters) {
     uint32_t n = *n_visible;
     if (n > n_bound) n = n_bound;
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && counters->instances > capacity) counters->overflow = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && counters->bin_entries > capacity) counters->overflow = 1;
     if (blockIdx.x * BLOCK >= n) return;
 
     bool valid = j < n;
@@ -659,6 +672,12 @@ __global__ __launch_bounds__(BLOCK) void k_duplicate(const uint32_t* __restrict_
         o = off[j];
         cnt = tiles_sorted[j];
         box = aabb[g];
+        if (shift) {  // tile box -> box of (tile >> shift) bins, upper bounds exclusive
+            box.z = (unsigned short)(((box.z - 1u) >> shift) + 1u);
+            box.w = (unsigned short)(((box.w - 1u) >> shift) + 1u);
+            box.x = (unsigned short)(box.x >> shift);
+            box.y = (unsigned short)(box.y >> shift);
+        }
         if ((uint64_t)o + cnt > capacity) valid = false;  // overflow: frame is re-run after growing
     }
     const bool big = valid && cnt >= WAVE;
@@ -689,11 +708,267 @@ __global__ __launch_bounds__(BLOCK) void k_duplicate(const uint32_t* __restrict_
 
 void launch_duplicate(const uint32_t* order, const uint32_t* off, const uint32_t* tiles_sorted,
                       const ushort4* aabb, const uint32_t* n_visible, uint32_t n_bound, uint32_t tiles_x,
-                      uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,
+                      int shift, uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,
                       hipStream_t s) {
     if (n_bound == 0) return;
     hipLaunchKernelGGL(k_duplicate, dim3((n_bound + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, order, off,
-                       tiles_sorted, aabb, n_visible, n_bound, tiles_x, capacity, inst_tile, inst_gid, counters);
+                       tiles_sorted, aabb, n_visible, n_bound, tiles_x, shift, capacity, inst_tile, inst_gid, counters);
+}
+
+// ---------------------------------------------------------------------------------------
+// Hierarchical binning: per-tile lists without sorting the D instances.
+//
+// The screen is cut into <= 256 bins of S x S tiles.  Level 1 (existing kernels) lists, per bin, the
+// Gaussians whose tile box touches it, in depth order: a scan, k_duplicate on bin boxes and ONE stable
+// 8-bit radix pass over E1 ~ 1.2 V entries -- instead of two passes over D ~ 10 V.  Level 2 (below)
+// expands each bin's list into its S*S tiles: 256-candidate chunks count per tile (k_bin_count), the
+// per-tile counts are scanned over chunks and over tiles (k_bin_scan, k_tile_scan -> the ranges and D),
+// and k_bin_fill writes every Gaussian id at  range.start + chunk prefix + rank-in-chunk,  the rank
+// coming from a wave64 ballot per tile.  Depth order is preserved at every step (stable radix pass,
+// chunks in order, lanes in order), so each tile's list equals the reference's stably sorted payload.
+// The instance data moved through HBM drops from ~48 B to ~4 B per instance.
+// ---------------------------------------------------------------------------------------
+struct BinArgs {
+    const uint32_t* cand;         // bin-major, depth-ordered Gaussian ids (level-1 output)
+    const uint32_t* bin_count;    // [256] candidates per bin (the radix pass's digit totals)
+    const ushort4* aabb;
+    uint32_t* chunk_hist;         // [chunk][S*S]: count, then exclusive prefix over the bin's chunks
+    uint32_t* tile_total;         // [T]
+    uint32_t* ranges;             // [T][2]
+    uint32_t* sorted_gid;         // [capacity]
+    Counters* counters;
+    uint32_t capacity;
+    uint32_t tiles_x, tiles_y, bins_x;
+    int shift;                    // log2(S)
+    uint32_t max_chunks;
+};
+
+constexpr int kBinChunk = 256;    // candidates per chunk (= one workgroup)
+constexpr int kMaxBinTiles = 1024;
+constexpr int kBinGrid = 2048;    // persistent grid striding over the (device-resident) chunk count
+
+// Offsets and chunk prefixes of all bins (once per block); returns the total number of chunks.
+__device__ __forceinline__ uint32_t bin_prepare(const BinArgs& a, uint32_t* s_off, uint32_t* s_cpre, uint32_t* scratch) {
+    const int tid = threadIdx.x;
+    const uint32_t c = a.bin_count[tid];
+    uint32_t total, total_chunks;
+    const uint32_t off = block_excl_scan<BLOCK>(c, scratch, &total);
+    const uint32_t nch = (c + kBinChunk - 1) / kBinChunk;
+    const uint32_t cpre = block_excl_scan<BLOCK>(nch, scratch, &total_chunks);
+    s_off[tid] = off;
+    s_cpre[tid] = cpre;
+    __syncthreads();
+    return total_chunks;
+}
+
+// chunk id -> (bin, first candidate, candidate count); uniform binary search over the 256 chunk prefixes
+__device__ __forceinline__ void bin_locate(const BinArgs& a, const uint32_t* s_off, const uint32_t* s_cpre, uint32_t chunk,
+                                           uint32_t& bin, uint32_t& first, uint32_t& count) {
+    uint32_t lo = 0, hi = 256;  // last bin whose chunk prefix is <= chunk and that owns chunks
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_cpre[mid] <= chunk) lo = mid; else hi = mid;
+    }
+    // empty bins share the prefix of their successor: step forward to the owner of this chunk
+    while (a.bin_count[lo] == 0) ++lo;
+    bin = lo;
+    const uint32_t q = chunk - s_cpre[bin];
+    first = s_off[bin] + q * kBinChunk;
+    const uint32_t end = s_off[bin] + a.bin_count[bin];
+    count = min((uint32_t)kBinChunk, end - first);
+}
+
+// candidate's tile box clipped to the bin, in bin-local tile coordinates (upper bounds exclusive)
+__device__ __forceinline__ void bin_local_box(const BinArgs& a, uint32_t bin, ushort4 box, int& lx0, int& ly0, int& lx1,
+                                              int& ly1) {
+    const int S = 1 << a.shift;
+    const int ox = (int)(bin % a.bins_x) << a.shift, oy = (int)(bin / a.bins_x) << a.shift;
+    lx0 = max((int)box.x, ox) - ox;
+    ly0 = max((int)box.y, oy) - oy;
+    lx1 = min((int)box.z, ox + S) - ox;
+    ly1 = min((int)box.w, oy + S) - oy;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bin_count(BinArgs a) {
+    __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
+    __shared__ uint32_t s_hist[kMaxBinTiles];
+    const uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
+    const int tid = threadIdx.x, S = 1 << a.shift, SS = S * S;
+    for (uint32_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+        uint32_t bin, first, count;
+        bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
+        for (int t = tid; t < SS; t += BLOCK) s_hist[t] = 0;
+        __syncthreads();
+        if ((uint32_t)tid < count) {
+            int lx0, ly0, lx1, ly1;
+            bin_local_box(a, bin, a.aabb[a.cand[first + tid]], lx0, ly0, lx1, ly1);
+            for (int y = ly0; y < ly1; ++y)
+                for (int x = lx0; x < lx1; ++x) atomicAdd(&s_hist[(y << a.shift) + x], 1u);
+        }
+        __syncthreads();
+        uint32_t* out = a.chunk_hist + (size_t)chunk * SS;
+        for (int t = tid; t < SS; t += BLOCK) out[t] = s_hist[t];
+    }
+}
+
+// One block per bin: for each of its tiles, exclusive prefix of the chunk counts (in place) and the tile total.
+__global__ __launch_bounds__(BLOCK) void k_bin_scan(BinArgs a) {
+    __shared__ uint32_t scratch[8];
+    const int tid = threadIdx.x, S = 1 << a.shift, SS = S * S;
+    const uint32_t bin = blockIdx.x;
+    const uint32_t c = a.bin_count[tid];
+    const uint32_t nch = (c + kBinChunk - 1) / kBinChunk;
+    uint32_t total_chunks;
+    const uint32_t cpre = block_excl_scan<BLOCK>(nch, scratch, &total_chunks);
+    __shared__ uint32_t s_first, s_n;
+    if ((uint32_t)tid == bin) {
+        s_first = cpre;
+        s_n = nch;
+    }
+    __syncthreads();
+    const uint32_t first = s_first, n = s_n;
+    const uint32_t ox = (bin % a.bins_x) << a.shift, oy = (bin / a.bins_x) << a.shift;
+    for (int t = tid; t < SS; t += BLOCK) {
+        uint32_t running = 0;
+        uint32_t* p = a.chunk_hist + (size_t)first * SS + t;
+        for (uint32_t q = 0; q < n; ++q, p += SS) {
+            const uint32_t v = *p;
+            *p = running;
+            running += v;
+        }
+        const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
+        if (x < a.tiles_x && y < a.tiles_y) a.tile_total[y * a.tiles_x + x] = running;
+    }
+}
+
+// Single block: exclusive scan of the per-tile totals -> ranges (absent tiles stay (0,0) like the
+// reference's zero-filled tileBoundaryBuffer), D -> counters.
+__global__ __launch_bounds__(1024) void k_tile_scan(BinArgs a) {
+    __shared__ uint32_t scratch[16];
+    const uint32_t T = a.tiles_x * a.tiles_y;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < T; base += 4096) {
+        const uint32_t i0 = base + threadIdx.x * 4;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = i0 + k < T ? a.tile_total[i0 + k] : 0;
+            sum += v[k];
+        }
+        uint32_t total;
+        uint32_t excl = running + block_excl_scan<1024>(sum, scratch, &total);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < T) {
+                // clamped to the list's capacity: an overflowing frame is re-run, but must not read past it
+                a.ranges[2 * (i0 + k)] = v[k] ? min(excl, a.capacity) : 0u;
+                a.ranges[2 * (i0 + k) + 1] = v[k] ? min(excl + v[k], a.capacity) : 0u;
+            }
+            excl += v[k];
+        }
+        running += total;
+    }
+    if (threadIdx.x == 0) {
+        a.counters->instances = running;
+        if (running > a.capacity) a.counters->overflow = 1;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
+    __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
+    __shared__ uint32_t s_wcnt[4][kMaxBinTiles];  // per-wave count per tile, then base position per (wave, tile)
+    const uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int S = 1 << a.shift, SS = S * S;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+        uint32_t bin, first, count;
+        bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
+        const bool have = (uint32_t)tid < count;
+        uint32_t g = 0;
+        int lx0 = 0, ly0 = 0, lx1 = 0, ly1 = 0;
+        if (have) {
+            g = a.cand[first + tid];
+            bin_local_box(a, bin, a.aabb[g], lx0, ly0, lx1, ly1);
+        }
+        // the wave only needs to visit the union of its candidates' local boxes
+        int wx0 = have ? lx0 : S, wy0 = have ? ly0 : S, wx1 = have ? lx1 : 0, wy1 = have ? ly1 : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            wx0 = min(wx0, __shfl_xor(wx0, d, WAVE));
+            wy0 = min(wy0, __shfl_xor(wy0, d, WAVE));
+            wx1 = max(wx1, __shfl_xor(wx1, d, WAVE));
+            wy1 = max(wy1, __shfl_xor(wy1, d, WAVE));
+        }
+        __syncthreads();  // previous chunk's positions are no longer read
+        for (int t = tid; t < SS; t += BLOCK) {
+            s_wcnt[0][t] = 0;
+            s_wcnt[1][t] = 0;
+            s_wcnt[2][t] = 0;
+            s_wcnt[3][t] = 0;
+        }
+        __syncthreads();
+        for (int y = wy0; y < wy1; ++y)
+            for (int x = wx0; x < wx1; ++x) {
+                const bool in = have && x >= lx0 && x < lx1 && y >= ly0 && y < ly1;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(in);
+                if (lane == 0) s_wcnt[w][(y << a.shift) + x] = (uint32_t)__popcll(m);
+            }
+        __syncthreads();
+        const uint32_t ox = (bin % a.bins_x) << a.shift, oy = (bin / a.bins_x) << a.shift;
+        const uint32_t* prefix = a.chunk_hist + (size_t)chunk * SS;
+        for (int t = tid; t < SS; t += BLOCK) {
+            const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
+            const uint32_t c0 = s_wcnt[0][t], c1 = s_wcnt[1][t], c2 = s_wcnt[2][t];
+            uint32_t base = 0;
+            if (x < a.tiles_x && y < a.tiles_y) base = a.ranges[2 * (y * a.tiles_x + x)] + prefix[t];
+            s_wcnt[0][t] = base;
+            s_wcnt[1][t] = base + c0;
+            s_wcnt[2][t] = base + c0 + c1;
+            s_wcnt[3][t] = base + c0 + c1 + c2;
+        }
+        __syncthreads();
+        for (int y = wy0; y < wy1; ++y)
+            for (int x = wx0; x < wx1; ++x) {
+                const bool in = have && x >= lx0 && x < lx1 && y >= ly0 && y < ly1;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(in);
+                if (in) {
+                    const uint32_t pos = s_wcnt[w][(y << a.shift) + x] + (uint32_t)__popcll(m & lt_mask);
+                    if (pos < a.capacity) a.sorted_gid[pos] = g;
+                }
+            }
+    }
+}
+
+static BinArgs bin_args(const BinLaunch& b) {
+    BinArgs a;
+    a.cand = b.cand;
+    a.bin_count = b.bin_count;
+    a.aabb = b.aabb;
+    a.chunk_hist = b.chunk_hist;
+    a.tile_total = b.tile_total;
+    a.ranges = b.ranges;
+    a.sorted_gid = b.sorted_gid;
+    a.counters = b.counters;
+    a.capacity = b.capacity;
+    a.tiles_x = b.tiles_x;
+    a.tiles_y = b.tiles_y;
+    a.bins_x = b.bins_x;
+    a.shift = b.shift;
+    a.max_chunks = b.max_chunks;
+    return a;
+}
+
+void launch_bin_ranges(const BinLaunch& b, hipStream_t s) {
+    const BinArgs a = bin_args(b);
+    hipLaunchKernelGGL(k_bin_count, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_bin_scan, dim3(b.bins), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, a);
+}
+
+void launch_bin_fill(const BinLaunch& b, hipStream_t s) {
+    hipLaunchKernelGGL(k_bin_fill, dim3(kBinGrid), dim3(BLOCK), 0, s, bin_args(b));
 }
 
 // ---------------------------------------------------------------------------------------
