@@ -744,7 +744,6 @@ struct BinArgs {
 };
 
 constexpr int kBinChunk = 256;    // candidates per chunk (= one workgroup)
-constexpr int kMaxBinTiles = 1024;
 constexpr int kBinGrid = 2048;    // persistent grid striding over the (device-resident) chunk count
 
 // Offsets and chunk prefixes of all bins (once per block); returns the total number of chunks.
@@ -790,25 +789,77 @@ __device__ __forceinline__ void bin_local_box(const BinArgs& a, uint32_t bin, us
     ly1 = min((int)box.w, oy + S) - oy;
 }
 
+// Coverage of a candidate's bin-local box as bit masks over the bin's S*S tiles: tile t = y*S + x lives in
+// bit (t % 64) of word (t / 64), i.e. lane (t % 64) "owns" tile t in register slot t / 64.  R = S*S/64 words.
+template <int R>
+__device__ __forceinline__ void bin_cover_masks(int shift, int lx0, int ly0, int lx1, int ly1, uint64_t (&m)[R]) {
+    const int S = 1 << shift;
+    const int rows_per_word = 64 >> shift;  // 8, 4, 2 for S = 8, 16, 32
+    const uint64_t rowbits = lx1 > lx0 ? ((lx1 - lx0 >= 64 ? ~0ull : ((1ull << (lx1 - lx0)) - 1ull)) << lx0) : 0ull;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint64_t w = 0;
+        for (int yy = 0; yy < rows_per_word; ++yy) {
+            const int y = r * rows_per_word + yy;
+            if (y >= ly0 && y < ly1) w |= rowbits << (yy * S);
+        }
+        m[r] = w;
+    }
+}
+
+// Per-wave walk over its 64 candidates with lanes transposed onto tiles: for candidate i the coverage word is
+// broadcast (v_readlane) and used directly as the lane predicate (inverse ballot), so "append candidate i to
+// the lists of the tiles it covers, in order" costs a handful of instructions and needs no ranking at all --
+// each lane just advances the cursor of the tile(s) it owns.  FILL = false only counts.
+template <int R, bool FILL>
+__device__ __forceinline__ void bin_walk(const uint64_t (&m)[R], uint32_t g, uint32_t (&cursor)[R], uint32_t nvalid,
+                                         uint32_t* __restrict__ out, uint32_t capacity) {
+    for (uint32_t i = 0; i < nvalid; ++i) {
+        const uint32_t gi = __builtin_amdgcn_readlane(g, i);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m[r], i);
+            const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m[r] >> 32), i);
+            const uint64_t cm = ((uint64_t)hi << 32) | lo;
+            if (cm == 0) continue;  // uniform
+            if (__builtin_amdgcn_inverse_ballot_w64(cm)) {
+                if (FILL && cursor[r] < capacity) out[cursor[r]] = gi;
+                cursor[r] += 1;
+            }
+        }
+    }
+}
+
+template <int R>
 __global__ __launch_bounds__(BLOCK) void k_bin_count(BinArgs a) {
     __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
-    __shared__ uint32_t s_hist[kMaxBinTiles];
+    __shared__ uint32_t s_wcnt[4][64 * R];
     const uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
-    const int tid = threadIdx.x, S = 1 << a.shift, SS = S * S;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    constexpr int SS = 64 * R;
     for (uint32_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
         uint32_t bin, first, count;
         bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
-        for (int t = tid; t < SS; t += BLOCK) s_hist[t] = 0;
-        __syncthreads();
-        if ((uint32_t)tid < count) {
-            int lx0, ly0, lx1, ly1;
-            bin_local_box(a, bin, a.aabb[a.cand[first + tid]], lx0, ly0, lx1, ly1);
-            for (int y = ly0; y < ly1; ++y)
-                for (int x = lx0; x < lx1; ++x) atomicAdd(&s_hist[(y << a.shift) + x], 1u);
+        const bool have = (uint32_t)tid < count;
+        uint64_t m[R];
+        uint32_t g = 0;
+        int lx0 = 0, ly0 = 0, lx1 = 0, ly1 = 0;
+        if (have) {
+            g = a.cand[first + tid];
+            bin_local_box(a, bin, a.aabb[g], lx0, ly0, lx1, ly1);
         }
+        bin_cover_masks<R>(a.shift, lx0, ly0, lx1, ly1, m);
+        uint32_t cursor[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) cursor[r] = 0;
+        const uint32_t nvalid = count > (uint32_t)w * WAVE ? min((uint32_t)WAVE, count - w * WAVE) : 0;
+        bin_walk<R, false>(m, g, cursor, nvalid, nullptr, 0);
+        __syncthreads();  // previous chunk's totals have been read
+#pragma unroll
+        for (int r = 0; r < R; ++r) s_wcnt[w][r * 64 + lane] = cursor[r];
         __syncthreads();
         uint32_t* out = a.chunk_hist + (size_t)chunk * SS;
-        for (int t = tid; t < SS; t += BLOCK) out[t] = s_hist[t];
+        for (int t = tid; t < SS; t += BLOCK) out[t] = s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t];
     }
 }
 
@@ -875,69 +926,50 @@ __global__ __launch_bounds__(1024) void k_tile_scan(BinArgs a) {
     }
 }
 
+template <int R>
 __global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
     __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
-    __shared__ uint32_t s_wcnt[4][kMaxBinTiles];  // per-wave count per tile, then base position per (wave, tile)
+    __shared__ uint32_t s_wcnt[4][64 * R];
     const uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const int S = 1 << a.shift, SS = S * S;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    constexpr int SS = 64 * R;
+    const int S = 1 << a.shift;
     for (uint32_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
         uint32_t bin, first, count;
         bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
         const bool have = (uint32_t)tid < count;
+        uint64_t m[R];
         uint32_t g = 0;
         int lx0 = 0, ly0 = 0, lx1 = 0, ly1 = 0;
         if (have) {
             g = a.cand[first + tid];
             bin_local_box(a, bin, a.aabb[g], lx0, ly0, lx1, ly1);
         }
-        // the wave only needs to visit the union of its candidates' local boxes
-        int wx0 = have ? lx0 : S, wy0 = have ? ly0 : S, wx1 = have ? lx1 : 0, wy1 = have ? ly1 : 0;
+        bin_cover_masks<R>(a.shift, lx0, ly0, lx1, ly1, m);
+        const uint32_t nvalid = count > (uint32_t)w * WAVE ? min((uint32_t)WAVE, count - w * WAVE) : 0;
+        // pass 1: how many of this wave's candidates land in each tile
+        uint32_t cursor[R];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            wx0 = min(wx0, __shfl_xor(wx0, d, WAVE));
-            wy0 = min(wy0, __shfl_xor(wy0, d, WAVE));
-            wx1 = max(wx1, __shfl_xor(wx1, d, WAVE));
-            wy1 = max(wy1, __shfl_xor(wy1, d, WAVE));
-        }
-        __syncthreads();  // previous chunk's positions are no longer read
-        for (int t = tid; t < SS; t += BLOCK) {
-            s_wcnt[0][t] = 0;
-            s_wcnt[1][t] = 0;
-            s_wcnt[2][t] = 0;
-            s_wcnt[3][t] = 0;
-        }
+        for (int r = 0; r < R; ++r) cursor[r] = 0;
+        bin_walk<R, false>(m, g, cursor, nvalid, nullptr, 0);
+        __syncthreads();  // previous chunk's counts have been read
+#pragma unroll
+        for (int r = 0; r < R; ++r) s_wcnt[w][r * 64 + lane] = cursor[r];
         __syncthreads();
-        for (int y = wy0; y < wy1; ++y)
-            for (int x = wx0; x < wx1; ++x) {
-                const bool in = have && x >= lx0 && x < lx1 && y >= ly0 && y < ly1;
-                const uint64_t m = __builtin_amdgcn_ballot_w64(in);
-                if (lane == 0) s_wcnt[w][(y << a.shift) + x] = (uint32_t)__popcll(m);
-            }
-        __syncthreads();
+        // start of this wave's run in each tile's list: range start + earlier chunks + earlier waves
         const uint32_t ox = (bin % a.bins_x) << a.shift, oy = (bin / a.bins_x) << a.shift;
         const uint32_t* prefix = a.chunk_hist + (size_t)chunk * SS;
-        for (int t = tid; t < SS; t += BLOCK) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = r * 64 + lane;
             const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
-            const uint32_t c0 = s_wcnt[0][t], c1 = s_wcnt[1][t], c2 = s_wcnt[2][t];
             uint32_t base = 0;
             if (x < a.tiles_x && y < a.tiles_y) base = a.ranges[2 * (y * a.tiles_x + x)] + prefix[t];
-            s_wcnt[0][t] = base;
-            s_wcnt[1][t] = base + c0;
-            s_wcnt[2][t] = base + c0 + c1;
-            s_wcnt[3][t] = base + c0 + c1 + c2;
+            for (int k = 0; k < w; ++k) base += s_wcnt[k][t];
+            cursor[r] = base;
         }
-        __syncthreads();
-        for (int y = wy0; y < wy1; ++y)
-            for (int x = wx0; x < wx1; ++x) {
-                const bool in = have && x >= lx0 && x < lx1 && y >= ly0 && y < ly1;
-                const uint64_t m = __builtin_amdgcn_ballot_w64(in);
-                if (in) {
-                    const uint32_t pos = s_wcnt[w][(y << a.shift) + x] + (uint32_t)__popcll(m & lt_mask);
-                    if (pos < a.capacity) a.sorted_gid[pos] = g;
-                }
-            }
+        // pass 2: append, in candidate order
+        bin_walk<R, true>(m, g, cursor, nvalid, a.sorted_gid, a.capacity);
     }
 }
 
@@ -962,13 +994,18 @@ static BinArgs bin_args(const BinLaunch& b) {
 
 void launch_bin_ranges(const BinLaunch& b, hipStream_t s) {
     const BinArgs a = bin_args(b);
-    hipLaunchKernelGGL(k_bin_count, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
+    if (b.shift == 3) hipLaunchKernelGGL(k_bin_count<1>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
+    else if (b.shift == 4) hipLaunchKernelGGL(k_bin_count<4>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(k_bin_count<16>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
     hipLaunchKernelGGL(k_bin_scan, dim3(b.bins), dim3(BLOCK), 0, s, a);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, a);
 }
 
 void launch_bin_fill(const BinLaunch& b, hipStream_t s) {
-    hipLaunchKernelGGL(k_bin_fill, dim3(kBinGrid), dim3(BLOCK), 0, s, bin_args(b));
+    const BinArgs a = bin_args(b);
+    if (b.shift == 3) hipLaunchKernelGGL(k_bin_fill<1>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
+    else if (b.shift == 4) hipLaunchKernelGGL(k_bin_fill<4>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(k_bin_fill<16>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -38,8 +38,9 @@ def test_config_a_stages_and_pixels(pkg, oracle, gpu):
     np.testing.assert_array_equal(bgra, oracle.pack_bgra8(ref["image"]))
 
 
-@pytest.mark.parametrize("w,h", [(200, 120), (33, 17), (16, 16), (1, 1), (641, 359)])
+@pytest.mark.parametrize("w,h", [(200, 120), (33, 17), (16, 16), (1, 1), (641, 359), (4100, 2200), (7680, 4320)])
 def test_ragged_resolutions(pkg, oracle, gpu, w, h):
+    """Odd sizes, single-tile frames, and the three bin sizes of the tile binning (8x8, 16x16, 32x32 tiles)."""
     rec = pkg.synth.synth_records(3000, seed=3, kind="A")
     scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
     compare_stages(pkg, rend, u, ref)
