@@ -23,8 +23,7 @@ BLOB_PLANES = 59
 
 STAGES = dict(tiles=(0, np.uint32), depth=(1, np.float32), radius=(2, np.float32), aabb=(3, np.uint16),
               conic_opacity=(4, np.float32), uv_rg=(5, np.float32), b=(6, np.float32),
-              depth_order=(7, np.uint32), offsets=(8, np.uint32), instance_tile=(9, np.uint32),
-              instance_gid=(10, np.uint32), sorted_tile=(11, np.uint32), sorted_gid=(12, np.uint32),
+              depth_order=(7, np.uint32), sorted_tile=(11, np.uint32), sorted_gid=(12, np.uint32),
               ranges=(13, np.uint32))
 
 # every symbol include/gs3d_hip.h declares
@@ -32,8 +31,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_scene_from_vertices", "gs_scene_from_device_blob", "gs_scene_blob_floats", "gs_scene_blob",
            "gs_scene_num_vertices", "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
-           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_debug_taps",
-           "gs_set_frames_in_flight", "gs_get_timing_totals",
+           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_get_timing_totals",
            "gs_get_stats", "gs_debug_download", "gs_renderer_stream"]
 
 
@@ -41,7 +39,8 @@ class FrameStats(C.Structure):
     _fields_ = [("num_gaussians", C.c_uint64), ("num_visible", C.c_uint64), ("num_instances", C.c_uint64),
                 ("instance_capacity", C.c_uint64), ("ms_preprocess", C.c_float), ("ms_prefix_sum", C.c_float),
                 ("ms_preprocess_sort", C.c_float), ("ms_sort", C.c_float), ("ms_tile_boundary", C.c_float),
-                ("ms_render", C.c_float), ("ms_total", C.c_float), ("retries", C.c_uint32)]
+                ("ms_render", C.c_float), ("ms_total", C.c_float), ("retries", C.c_uint32),
+                ("num_bin_entries", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -218,9 +217,6 @@ class Renderer:
     def set_timing(self, enabled):
         _check(lib().gs_set_timing(self._h, C.c_int(int(enabled))))
 
-    def set_debug_taps(self, enabled):
-        _check(lib().gs_set_debug_taps(self._h, C.c_int(int(enabled))))
-
     def set_frames_in_flight(self, frames):
         _check(lib().gs_set_frames_in_flight(self._h, C.c_int(int(frames))))
 
@@ -242,8 +238,7 @@ class Renderer:
         st = self.stats()
         n, v, d = st.num_gaussians, st.num_visible, min(st.num_instances, st.instance_capacity)
         count = {"tiles": n, "depth": n, "radius": n, "aabb": 4 * n, "conic_opacity": 4 * n, "uv_rg": 4 * n,
-                 "b": n, "depth_order": v, "offsets": v, "instance_tile": d, "instance_gid": d,
-                 "sorted_tile": d, "sorted_gid": d}.get(name)
+                 "b": n, "depth_order": v, "sorted_tile": d, "sorted_gid": d}.get(name)
         if name == "ranges":
             w, h = int(uniforms["width"][0]), int(uniforms["height"][0])
             count = 2 * ((w + 15) // 16) * ((h + 15) // 16)

@@ -193,7 +193,6 @@ struct FrameBuffers {
     DevBuf<uint32_t> ranges;
     DevBuf<uint32_t> sorted, chunk_hist, tile_total;  // hierarchical binning
     DevBuf<gs::Counters> counters;
-    DevBuf<uint32_t> tap_tile, tap_gid;
     bool ready = false;
 
     void init(size_t n, uint32_t capacity) {
@@ -245,8 +244,6 @@ struct gs_renderer {
 
     gs_scene* scene = nullptr;
     bool timing = true;
-    bool keep_taps = false;  // debug: preserve the pre-sort instance arrays for gs_debug_download
-    bool use_binning = true; // GS_TILE_PATH=sort selects the instance-sort path (A/B measurements)
 
     FrameBuffers sets[kMaxInFlight];
     int num_sets = 1;
@@ -266,10 +263,7 @@ struct gs_renderer {
     double total_ms[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t total_frames = 0;
 
-    uint32_t* sorted_tile = nullptr;  // result buffers of the last enqueued frame
-    uint32_t* sorted_gid = nullptr;
-    uint32_t* inst_tile = nullptr;
-    uint32_t* inst_gid = nullptr;
+    uint32_t* sorted_gid = nullptr;  // result buffers of the last enqueued frame
     uint32_t* depth_order = nullptr;
     uint64_t num_tiles = 0;
 
@@ -296,7 +290,6 @@ struct gs_renderer {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(gs::Counters), hipHostMallocDefault));
             *sl.h_counters = gs::Counters{};
         }
-        if (const char* e = std::getenv("GS_TILE_PATH")) use_binning = std::string(e) != "sort";
         const uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(scene->n));
         capacity = static_cast<uint32_t>(std::min<uint64_t>(want, 0xFFFFF000ull));
         sets[0].init(scene->n, capacity);
@@ -315,8 +308,7 @@ struct gs_renderer {
         hipStream_t stream = fb.stream;
         auto &tiles = fb.tiles, &tiles_sorted = fb.tiles_sorted, &offsets = fb.offsets, &block_hist = fb.block_hist,
              &digit_total = fb.digit_total, &scan_partial = fb.scan_partial, &ranges = fb.ranges,
-             &tap_tile = fb.tap_tile, &tap_gid = fb.tap_gid, &sorted = fb.sorted, &chunk_hist = fb.chunk_hist,
-             &tile_total = fb.tile_total;
+             &sorted = fb.sorted, &chunk_hist = fb.chunk_hist, &tile_total = fb.tile_total;
         auto &depth = fb.depth, &radius = fb.radius, &bch = fb.bch;
         auto &aabb = fb.aabb;
         auto &conic_op = fb.conic_op, &uv_rg = fb.uv_rg;
@@ -375,12 +367,8 @@ struct gs_renderer {
                 p.blocks = blocks;
                 p.first = pass == 0;
                 if (pass == 3) {
-                    if (use_binning) {  // per Gaussian: how many bins its tile box touches
-                        p.gather_aabb = aabb.p;
-                        p.bin_shift = bin_shift;
-                    } else {
-                        p.gather_tiles = tiles.p;
-                    }
+                    p.gather_aabb = aabb.p;  // per Gaussian: how many bins its tile box touches
+                    p.bin_shift = bin_shift;
                     p.tiles_sorted = tiles_sorted.p;
                 }
                 gs::launch_radix_pass(p, stream);
@@ -391,7 +379,7 @@ struct gs_renderer {
         }
         if (timing) HIP_CHECK(hipEventRecord(ev[2], stream));
 
-        if (use_binning) {
+        {
             // ---- level 1: (bin, Gaussian) candidates in depth order, one stable pass by bin ----
             gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, &cnt->visible, n, scan_partial.p, &cnt->bin_entries, stream);
             if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
@@ -436,65 +424,6 @@ struct gs_renderer {
             gs::launch_bin_fill(b, stream);
             if (timing) HIP_CHECK(hipEventRecord(ev[8], stream));
             sorted_gid = sorted.p;
-            sorted_tile = nullptr;
-            inst_tile = inst_gid = nullptr;
-        } else {
-            // ---- offsets = exclusive scan of tiles_overlap in depth order; D -> counters ----
-            gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, &cnt->visible, n, scan_partial.p, &cnt->bin_entries, stream);
-            if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
-
-            // ---- duplicate ----
-            inst_tile = ikeys[0].p;
-            inst_gid = ivals[0].p;
-            gs::launch_duplicate(depth_order, offsets.p, tiles_sorted.p, aabb.p, &cnt->visible, n, tx, 0, capacity,
-                                 inst_tile, inst_gid, cnt, stream);
-            HIP_CHECK(hipMemcpyAsync(&cnt->instances, &cnt->bin_entries, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-            if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
-            if (keep_taps) {  // the tile sort ping-pongs over the duplicate output
-                tap_tile.ensure(capacity);
-                tap_gid.ensure(capacity);
-                HIP_CHECK(hipMemcpyAsync(tap_tile.p, inst_tile, capacity * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-                HIP_CHECK(hipMemcpyAsync(tap_gid.p, inst_gid, capacity * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-                inst_tile = tap_tile.p;
-                inst_gid = tap_gid.p;
-            }
-
-            // ---- stable sort by tile id (instances are already in depth order) ----
-            {
-                int bits = 0;
-                while ((1ull << bits) < num_tiles) ++bits;
-                const int passes = (bits + 7) / 8;
-                const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (capacity + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
-                int src = 0;
-                for (int pass = 0; pass < passes; ++pass) {
-                    gs::RadixPass p{};
-                    p.keys_in = ikeys[src].p;
-                    p.vals_in = ivals[src].p;
-                    p.keys_out = ikeys[src ^ 1].p;
-                    p.vals_out = ivals[src ^ 1].p;
-                    p.n_in = &cnt->instances;
-                    p.n_static = capacity;
-                    p.block_hist = block_hist.p;
-                    p.digit_total = digit_total.p;
-                    p.shift = pass * 8;
-                    p.bits = std::min(8, bits - pass * 8);
-                    p.blocks = blocks;
-                    p.first = 0;
-                    gs::launch_radix_pass(p, stream);
-                    src ^= 1;
-                }
-                sorted_tile = ikeys[src].p;
-                sorted_gid = ivals[src].p;
-            }
-            if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
-
-            // ---- tile ranges (Renderer.cpp:633 fill + tile_boundary) ----
-            HIP_CHECK(hipMemsetAsync(ranges.p, 0, 2 * num_tiles * sizeof(uint32_t), stream));
-            gs::launch_tile_ranges(sorted_tile, &cnt->instances, capacity, ranges.p, stream);
-            if (timing) {
-                HIP_CHECK(hipEventRecord(ev[6], stream));
-                HIP_CHECK(hipEventRecord(ev[8], stream));
-            }
         }
 
         // ---- blend ----
@@ -548,6 +477,7 @@ struct gs_renderer {
         st.num_gaussians = scene->n;
         st.num_visible = sl.h_counters->visible;
         st.num_instances = sl.h_counters->instances;
+        st.num_bin_entries = sl.h_counters->bin_entries;
         st.instance_capacity = capacity;
         auto span = [&](int a, int b) {
             float ms = 0.0f;
@@ -779,14 +709,6 @@ int gs_set_timing(gs_renderer* r, int enabled) {
     });
 }
 
-int gs_set_debug_taps(gs_renderer* r, int enabled) {
-    return guarded([&] {
-        if (!r) throw Error(GS_ERR_INVALID, "null argument");
-        r->drain();
-        r->keep_taps = enabled != 0;
-    });
-}
-
 int gs_set_frames_in_flight(gs_renderer* r, int frames) {
     return guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "null argument");
@@ -846,16 +768,8 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
             case GS_STAGE_UV_RG: src = r->last_set->uv_rg.p; size = n * 16; break;
             case GS_STAGE_B: src = r->last_set->bch.p; size = n * 4; break;
             case GS_STAGE_DEPTH_ORDER: src = r->depth_order; size = v * 4; break;
-            case GS_STAGE_OFFSETS: src = r->last_set->offsets.p; size = v * 4; break;
-            case GS_STAGE_INSTANCE_TILE:
-            case GS_STAGE_INSTANCE_GID:
-                if (r->use_binning) throw Error(GS_ERR_INVALID, "the binning path has no unsorted instance list (GS_TILE_PATH=sort has)");
-                if (!r->keep_taps) throw Error(GS_ERR_INVALID, "enable gs_set_debug_taps before rendering to read pre-sort instances");
-                src = stage == GS_STAGE_INSTANCE_TILE ? r->inst_tile : r->inst_gid;
-                size = d * 4;
-                break;
             case GS_STAGE_SORTED_TILE:
-                if (!r->sorted_tile) {  // binning path: the tile id of list position i follows from the ranges
+                {   // the tile id of list position i follows from the ranges
                     if (bytes < d * 4) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
                     std::vector<uint32_t> rg(2 * r->num_tiles);
                     if (!rg.empty()) HIP_CHECK(hipMemcpy(rg.data(), r->last_set->ranges.p, rg.size() * 4, hipMemcpyDeviceToHost));
@@ -864,9 +778,6 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
                         for (uint64_t i = rg[2 * t]; i < std::min<uint64_t>(rg[2 * t + 1], d); ++i) out[i] = static_cast<uint32_t>(t);
                     return;
                 }
-                src = r->sorted_tile;
-                size = d * 4;
-                break;
             case GS_STAGE_SORTED_GID: src = r->sorted_gid; size = d * 4; break;
             case GS_STAGE_RANGES: src = r->last_set->ranges.p; size = r->num_tiles * 8; break;
             default: throw Error(GS_ERR_INVALID, "unknown stage");

@@ -101,10 +101,6 @@ struct BinLaunch {
 void launch_bin_ranges(const BinLaunch& b, hipStream_t s);  // k_bin_count, k_bin_scan, k_tile_scan
 void launch_bin_fill(const BinLaunch& b, hipStream_t s);    // k_bin_fill
 
-// tile_boundary.comp counterpart (ranges must be zero-filled before).
-void launch_tile_ranges(const uint32_t* sorted_tile, const uint32_t* n, uint32_t capacity, uint32_t* ranges,
-                        hipStream_t s);
-
 // render.comp counterpart.
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const AttrView& av, uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, hipStream_t s);

@@ -11,7 +11,7 @@
 //   k_radix_*      sort/hist.comp + sort/sort.comp (result: stable ascending order)
 //   k_scan_*       prefix_sum.comp:32-59 (result: prefix sums)
 //   k_duplicate    preprocess_sort.comp:31-61
-//   k_tile_ranges  tile_boundary.comp:22-50
+//   k_bin_*, k_tile_scan   preprocess_sort.comp + the tile part of the sort + tile_boundary.comp:22-50
 //   k_blend        render.comp:30-99
 #include "gs_kernels.h"
 
@@ -883,7 +883,18 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scan(BinArgs a) {
     for (int t = tid; t < SS; t += BLOCK) {
         uint32_t running = 0;
         uint32_t* p = a.chunk_hist + (size_t)first * SS + t;
-        for (uint32_t q = 0; q < n; ++q, p += SS) {
+        uint32_t q = 0;
+        for (; q + 8 <= n; q += 8, p += 8 * (size_t)SS) {  // 8 independent loads in flight per step
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)k * SS];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                p[(size_t)k * SS] = running;
+                running += v[k];
+            }
+        }
+        for (; q < n; ++q, p += SS) {
             const uint32_t v = *p;
             *p = running;
             running += v;
@@ -1006,37 +1017,6 @@ void launch_bin_fill(const BinLaunch& b, hipStream_t s) {
     if (b.shift == 3) hipLaunchKernelGGL(k_bin_fill<1>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
     else if (b.shift == 4) hipLaunchKernelGGL(k_bin_fill<4>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
     else hipLaunchKernelGGL(k_bin_fill<16>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
-}
-
-// ---------------------------------------------------------------------------------------
-// tile ranges.  tile_boundary.comp:22-50 (ranges zero-filled by the caller, Renderer.cpp:633).
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_tile_ranges(const uint32_t* __restrict__ sorted_tile,
-                                                       const uint32_t* n_ptr, uint32_t capacity,
-                                                       uint32_t* __restrict__ ranges) {
-    uint32_t n = *n_ptr;
-    if (n > capacity) n = capacity;
-    for (uint32_t index = blockIdx.x * BLOCK + threadIdx.x; index < n; index += gridDim.x * BLOCK) {
-        const uint32_t key = sorted_tile[index];
-        if (index == 0) {
-            ranges[key * 2] = index;
-        } else {
-            const uint32_t prev = sorted_tile[index - 1];
-            if (key != prev) {
-                ranges[key * 2] = index;
-                ranges[prev * 2 + 1] = index;
-            }
-        }
-        if (index == n - 1) ranges[key * 2 + 1] = n;
-    }
-}
-
-void launch_tile_ranges(const uint32_t* sorted_tile, const uint32_t* n, uint32_t capacity, uint32_t* ranges,
-                        hipStream_t s) {
-    if (capacity == 0) return;
-    uint32_t blocks = (capacity + BLOCK - 1) / BLOCK;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(blocks), dim3(BLOCK), 0, s, sorted_tile, n, capacity, ranges);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -30,19 +30,21 @@ import __graft_entry__ as entry  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def algorithmic_bytes(n, v, d, t, p):
-    """Implementation-independent HBM bytes per frame and pass."""
-    bits = max(1, math.ceil(math.log2(max(t, 2))))
-    tile_passes = math.ceil(bits / 8)
+def algorithmic_bytes(n, v, d, e1, t, p):
+    """Implementation-independent HBM bytes per frame and pass for this decomposition.
+    n Gaussians, v visible, d tile instances, e1 (bin, Gaussian) candidates, t tiles, p pixels."""
     return {
         # pos 12 + cov3d 24 per Gaussian; opacity 4 + SH 192 per visible; 52 B of attributes out; tiles 4
         "preprocess": n * (12 + 24) + v * (4 + 192) + v * 52 + n * 4,
+        # bins-per-Gaussian in, offsets out
         "prefix_sum": 8 * v,
-        "preprocess_sort": v * 20 + d * 8,
-        # depth order: 4 passes over V (key+id in, key+id out) + histogram reads;
-        # tile sort: passes over D (tile+id in/out) + histogram reads
-        "sort": 4 * (4 + 16) * v + tile_passes * (4 + 16) * d,
-        "tile_boundary": 4 * d + 8 * t,
+        # level-1 emit: id, offset, count, box per visible; (bin, id) per candidate
+        "preprocess_sort": v * 20 + e1 * 8,
+        # depth order: 4 passes over V (histogram read 4 + key/id in 8 + out 8); one pass over the E1 candidates;
+        # fill: candidate id 4 + box 8 in, Gaussian id 4 out per instance
+        "sort": 4 * (4 + 16) * v + (4 + 16) * e1 + 12 * e1 + 4 * d,
+        # per-tile counts: candidate id + box in; tile totals and ranges out
+        "tile_boundary": 12 * e1 + 12 * t,
         "render": 40 * d + 16 * p,
     }
 
@@ -134,15 +136,26 @@ def main():
 
     sums, frames = rend.timing_totals(reset=True)
     st = rend.stats()
+
+    # diagnostic only: the same frame with ONE frame in flight, so that per-pass spans are not stretched by
+    # the other streams' kernels (the timed region above overlaps frames; its spans include that contention)
+    rend.set_frames_in_flight(1)
+    for i in range(30):
+        submit(i)
+    rend.synchronize()
+    ssum, sframes = rend.timing_totals(reset=True)
     if rank == 0:
         fps = world * args.steps / elapsed
         T = ((w + 15) // 16) * ((h + 15) // 16)
-        nbytes = algorithmic_bytes(st.num_gaussians, st.num_visible, st.num_instances, T, w * h)
+        nbytes = algorithmic_bytes(st.num_gaussians, st.num_visible, st.num_instances, st.num_bin_entries, T, w * h)
         names = ["preprocess", "prefix_sum", "preprocess_sort", "sort", "tile_boundary", "render"]
         ms = {k: getattr(sums, "ms_" + k) / max(frames, 1) for k in names}
         per_pass = {k: {"ms": round(ms[k], 4), "alg_MB": round(nbytes[k] / 1e6, 2),
                         "GBps": round(nbytes[k] / 1e9 / (ms[k] * 1e-3), 1) if ms[k] > 0 else None} for k in names}
-        dom = max(names, key=lambda k: ms[k])
+        # dominant kernel = largest share of a frame's GPU time when frames run one at a time (k_blend here);
+        # its duration for the roofline is the span measured inside the timed (overlapped) region
+        serial = {k: getattr(ssum, "ms_" + k) / max(sframes, 1) for k in names}
+        dom = max(names, key=lambda k: serial[k])
         achieved = nbytes[dom] / 1e9 / (ms[dom] * 1e-3)
         result = {
             "metric": "frames/sec at 1920x1080, 1M Gaussians",
@@ -160,13 +173,14 @@ def main():
             "config": {"workload": f"S({n}) synthetic Gaussians, {w}x{h}, degree-3 SH, one camera pose per GPU "
                                    f"(BASELINE configs[1]; configs[3] when n_gpus>1)",
                        "gaussians": int(st.num_gaussians), "visible": int(st.num_visible),
-                       "instances": int(st.num_instances), "tiles": T, "output": "rgba32f" + ("+bgra8" if args.bgra8 else ""),
+                       "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries), "tiles": T, "output": "rgba32f" + ("+bgra8" if args.bgra8 else ""),
                        "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}"},
             "gpu_ms_per_frame": round(sums.ms_total / max(frames, 1), 4),
             "passes": per_pass,
+            "passes_serial_ms": {k: round(getattr(ssum, "ms_" + k) / max(sframes, 1), 4) for k in names + ["total"]},
             "roofline": {"kernel": {"render": "k_blend"}.get(dom, dom), "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, n, w, h),
                          "note": "blend is FP32-VALU bound, not HBM bound (DESIGN.md §5); frac is the HBM view"},
         }
         if not args.no_cpu_baseline:
@@ -175,6 +189,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(pass_name, n, w, h):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run (profiles/r01_pmc_hbm_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, KB -> bytes; see the file for the gfx950 caveats).
+    null when no counter run exists for this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            prof = json.load(f)
+        if [prof["gaussians"], prof["width"], prof["height"]] != [n, w, h]:
+            return None
+        k = prof["kernels"][{"render": "k_blend", "preprocess": "k_preprocess"}[pass_name]]
+        return int((k["fetch_kb"] * k.get("fetch_scale", 1.0) + k["write_kb"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(n, w, h):

@@ -71,6 +71,7 @@ typedef struct {
     float ms_render;
     float ms_total;
     uint32_t retries; /* frames re-run after growing the instance buffers */
+    uint32_t num_bin_entries; /* E1: (bin, Gaussian) candidates of the tile binning's first level */
 } gs_frame_stats;
 
 /* Stage taps for parity tests (the role of Buffer::download / assertEquals,
@@ -84,10 +85,7 @@ enum gs_stage {
     GS_STAGE_UV_RG = 5,          /* float[4N]  u v r g                                        */
     GS_STAGE_B = 6,              /* float[N]   b                                              */
     GS_STAGE_DEPTH_ORDER = 7,    /* uint32[V]  visible Gaussian ids, ascending (depth, id)    */
-    GS_STAGE_OFFSETS = 8,        /* uint32[V]  exclusive scan of tiles_overlap in that order  */
-    GS_STAGE_INSTANCE_TILE = 9,  /* uint32[D]  tile id per instance before the tile sort      */
-    GS_STAGE_INSTANCE_GID = 10,  /* uint32[D]  Gaussian id per instance before the tile sort  */
-    GS_STAGE_SORTED_TILE = 11,   /* uint32[D]  == sorted key >> 32 of the reference           */
+    GS_STAGE_SORTED_TILE = 11,   /* uint32[D]  == sorted key >> 32 of the reference (expanded from the ranges) */
     GS_STAGE_SORTED_GID = 12,    /* uint32[D]  == sorted payload of the reference             */
     GS_STAGE_RANGES = 13         /* uint32[2T] == tileBoundaryBuffer                          */
 };
@@ -166,8 +164,6 @@ int gs_set_frames_in_flight(gs_renderer* r, int frames);
 /* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
  * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
 int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset);
-/* Debug: keep a copy of the pre-sort instance arrays (GS_STAGE_INSTANCE_*) of each frame. */
-int gs_set_debug_taps(gs_renderer* r, int enabled);
 /* Renderer::retrieveTimestamps (Renderer.cpp:85-100) for the last frame; synchronizes. */
 int gs_get_stats(gs_renderer* r, gs_frame_stats* out);
 /* Copy a stage buffer of the last frame to host memory; synchronizes. */

@@ -13,11 +13,10 @@ pytestmark = pytest.mark.gpu
 PIXEL_TOL = 1e-4
 
 
-def _run(pkg, oracle, rec, w, h, camera=None, taps=True):
+def _run(pkg, oracle, rec, w, h, camera=None):
     verts, u_ref, ref = oracle_frame(oracle, rec, w, h, camera)
     scene = pkg.Scene.from_records(rec, device=0)
     rend = pkg.Renderer(scene)
-    rend.set_debug_taps(taps)
     cam = camera if camera is not None else pkg.make_camera()
     u = pkg.camera_uniforms(cam, w, h)
     assert u.tobytes() == u_ref.tobytes(), "Renderer::updateUniforms restatements disagree"
@@ -78,7 +77,7 @@ def test_instance_overflow_regrows(pkg, oracle, gpu):
     rec = pkg.synth.synth_records(300, seed=7, kind="A")
     rec[:, 55:58] = 1.5  # log-scale: sigma ~ 4.5 world units -> every splat covers the screen
     w, h = 1920, 1080
-    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h, taps=False)
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
     st = rend.stats()
     assert st.num_instances == len(ref["keys"])
     assert st.num_instances > (1 << 20) and st.retries >= 1
