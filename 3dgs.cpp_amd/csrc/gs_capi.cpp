@@ -116,7 +116,7 @@ namespace {
 constexpr uint64_t kMaxGaussians = 1ull << 31;  // ids and counts are 32-bit on the device
 
 void upload_vertices(gs_scene* s, const float* vertices, uint64_t n) {
-    // AoS GSScene::Vertex[n] -> 59 SoA planes (pos3, scale3, rot4, opacity, sh48)
+    // AoS GSScene::Vertex[n] -> blob: 11 SoA planes (pos3, scale3, rot4, opacity) + AoS SH block (48 per Gaussian)
     if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
     s->n = n;
     std::vector<float> planes(static_cast<size_t>(gs::P_COUNT) * n);
@@ -126,7 +126,7 @@ void upload_vertices(gs_scene* s, const float* vertices, uint64_t n) {
         for (int k = 0; k < 3; ++k) planes[(gs::P_SCALE + k) * n + i] = v[4 + k];
         for (int k = 0; k < 4; ++k) planes[(gs::P_ROT + k) * n + i] = v[8 + k];
         planes[static_cast<size_t>(gs::P_OPACITY) * n + i] = v[7];
-        for (int k = 0; k < 48; ++k) planes[(gs::P_SH + k) * n + i] = v[12 + k];
+        for (int k = 0; k < 48; ++k) planes[static_cast<size_t>(gs::P_SH) * n + i * 48 + k] = v[12 + k];
     }
     s->owned_blob.alloc(planes.size());
     s->blob = s->owned_blob.p;
@@ -623,7 +623,7 @@ int gs_scene_download_vertices(const gs_scene* s, float* vertices) {
             for (int k = 0; k < 3; ++k) v[4 + k] = planes[(gs::P_SCALE + k) * n + i];
             v[7] = planes[static_cast<size_t>(gs::P_OPACITY) * n + i];
             for (int k = 0; k < 4; ++k) v[8 + k] = planes[(gs::P_ROT + k) * n + i];
-            for (int k = 0; k < 48; ++k) v[12 + k] = planes[(gs::P_SH + k) * n + i];
+            for (int k = 0; k < 48; ++k) v[12 + k] = planes[static_cast<size_t>(gs::P_SH) * n + i * 48 + k];
         }
     });
 }

@@ -13,7 +13,8 @@ constexpr int kSortTileKeys = 2048;   // keys per radix tile (256 threads x 8)
 constexpr int kSortMaxBlocks = 1024;  // fixed sort grid (data-dependent sizes stay on the device)
 constexpr int kScanBlocks = 512;      // fixed scan grid
 
-// Packed SoA scene blob: plane p of Gaussian i is blob[p*n + i].
+// Packed scene blob (59 floats per Gaussian): planes 0..10 are SoA -- plane p of Gaussian i is blob[p*n + i] --
+// followed by the SH block as AoS: the 48 SH floats of Gaussian i are blob[11*n + 48*i .. +48).
 enum ScenePlane { P_POS = 0, P_SCALE = 3, P_ROT = 6, P_OPACITY = 10, P_SH = 11, P_COUNT = 59 };
 
 struct SceneView {

@@ -125,8 +125,9 @@ void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// preprocess.  One thread per Gaussian, SoA plane loads (coalesced 256 B per wave and plane);
-// the 48 SH planes are read only by lanes that survive every cull.
+// preprocess.  One thread per Gaussian; position / cov3D / opacity are SoA planes (coalesced 256 B per
+// wave and plane); the SH block is AoS (48 contiguous floats) and is read only by lanes that survive
+// every cull.
 // ---------------------------------------------------------------------------------------
 constexpr float SH_C0 = 0.28209479177387814f;  // common.glsl:16-33
 constexpr float SH_C1 = 0.4886025119029199f;
@@ -254,7 +255,20 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         float dz = pz - u.camera_position[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
         const float x = dx / len, y = dy / len, z = dz / len;
-        const float* __restrict__ sh = blob + (size_t)P_SH * N + i;
+        // the 48 SH floats of a Gaussian are contiguous (192 B = three 64-byte lines): only lanes that
+        // survived every cull fetch them, so SH traffic is 192 B per VISIBLE Gaussian
+        float sh[48];
+        {
+            const float4* __restrict__ shv = reinterpret_cast<const float4*>(blob + (size_t)P_SH * N) + (size_t)i * 12;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const float4 t = shv[q];
+                sh[4 * q + 0] = t.x;
+                sh[4 * q + 1] = t.y;
+                sh[4 * q + 2] = t.z;
+                sh[4 * q + 3] = t.w;
+            }
+        }
         float rgb[3];
         const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
                     C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
                     C3_6 = -0.5900435899266435f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-#define S(j) sh[(size_t)((j) * 3 + k) * N]
+#define S(j) sh[(j) * 3 + k]
             float c = SH_C0 * S(0);
             c -= SH_C1 * S(1) * y;
             c += SH_C1 * S(2) * z;

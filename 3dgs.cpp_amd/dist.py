@@ -9,32 +9,34 @@ import math
 
 import numpy as np
 
-BLOB_PLANES = 59  # pos 3, scale 3, rot 4, opacity 1, sh 48 (gs_kernels.h ScenePlane)
+BLOB_PLANES = 59  # floats per Gaussian: 11 SoA planes (pos 3, scale 3, rot 4, opacity 1) + AoS SH block of 48
 
 
 def pack_blob(vertices):
     """(n, 60) activated GSScene::Vertex rows -> packed SoA blob (59*n floats), plane-major."""
     v = np.ascontiguousarray(vertices).view(np.float32).reshape(-1, 60)
     n = len(v)
-    blob = np.empty((BLOB_PLANES, n), np.float32)
-    blob[0:3] = v[:, 0:3].T      # position xyz (w == 1 is implicit)
-    blob[3:6] = v[:, 4:7].T      # exp(scale)
-    blob[6:10] = v[:, 8:12].T    # rotation w x y z
-    blob[10] = v[:, 7]           # sigmoid(opacity)
-    blob[11:59] = v[:, 12:60].T  # 16 RGB triples
-    return blob.reshape(-1)
+    blob = np.empty(BLOB_PLANES * n, np.float32)
+    planes = blob[:11 * n].reshape(11, n)
+    planes[0:3] = v[:, 0:3].T      # position xyz (w == 1 is implicit)
+    planes[3:6] = v[:, 4:7].T      # exp(scale)
+    planes[6:10] = v[:, 8:12].T    # rotation w x y z
+    planes[10] = v[:, 7]           # sigmoid(opacity)
+    blob[11 * n:] = v[:, 12:60].reshape(-1)  # SH block, AoS: 16 RGB triples per Gaussian, contiguous
+    return blob
 
 
 def unpack_blob(blob, n):
     """Inverse of pack_blob -> (n, 60) float32."""
-    b = np.asarray(blob, np.float32).reshape(BLOB_PLANES, n)
+    blob = np.asarray(blob, np.float32).reshape(-1)
+    b = blob[:11 * n].reshape(11, n)
     v = np.zeros((n, 60), np.float32)
     v[:, 0:3] = b[0:3].T
     v[:, 3] = 1.0
     v[:, 4:7] = b[3:6].T
     v[:, 7] = b[10]
     v[:, 8:12] = b[6:10].T
-    v[:, 12:60] = b[11:59].T
+    v[:, 12:60] = blob[11 * n:].reshape(n, 48)
     return v
 
 

@@ -116,7 +116,8 @@ int gs_scene_from_records(const float* records, uint64_t n, int device, gs_scene
 int gs_scene_from_vertices(const float* vertices, uint64_t n, int device, gs_scene** out);
 
 /* Adopt a packed SoA blob already resident in HBM (gs_scene_blob_floats(n) floats:
- * pos[3][n] scale[3][n] rot[4][n] opacity[n] sh[48][n]); the caller keeps it alive.
+ * 11 SoA planes pos[3][n] scale[3][n] rot[4][n] opacity[n], then the SH block as AoS sh[n][48]);
+ * the caller keeps it alive.
  * This is the multi-GPU path: rank 0 builds the blob, RCCL broadcasts it, every rank
  * adopts its copy.  No reference counterpart (the reference is single-GPU). */
 int gs_scene_from_device_blob(float* d_blob, uint64_t n, int device, gs_scene** out);
