@@ -114,6 +114,7 @@ struct gs_scene {
 namespace {
 
 constexpr uint64_t kMaxGaussians = 1ull << 31;  // ids and counts are 32-bit on the device
+constexpr uint64_t kMaxInstances = (1ull << 30) - 4096;  // the per-tile lists live in one 4 GiB raw buffer
 
 void upload_vertices(gs_scene* s, const float* vertices, uint64_t n) {
     // AoS GSScene::Vertex[n] -> blob: 11 SoA planes (pos3, scale3, rot4, opacity) + AoS SH block (48 per Gaussian)
@@ -291,7 +292,7 @@ struct gs_renderer {
             *sl.h_counters = gs::Counters{};
         }
         const uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(scene->n));
-        capacity = static_cast<uint32_t>(std::min<uint64_t>(want, 0xFFFFF000ull));
+        capacity = static_cast<uint32_t>(std::min<uint64_t>(want, kMaxInstances));
         sets[0].init(scene->n, capacity);
     }
 
@@ -326,7 +327,7 @@ struct gs_renderer {
         const uint32_t bins_x = ((tx - 1) >> bin_shift) + 1, bins_y = ((ty - 1) >> bin_shift) + 1;
         const uint32_t bin_tiles = 1u << (2 * bin_shift);
         if (bin_tiles > 1024) throw Error(GS_ERR_INVALID, "resolution too large for the tile binning (max 8192 x 8192)");
-        const uint32_t max_chunks = capacity / 256 + 256;
+        const uint32_t max_chunks = capacity / 256 + 256;  // 64-candidate chunks; sized for E1 <= capacity / 4 (flagged otherwise)
         if (2 * nt > ranges.n || static_cast<size_t>(max_chunks) * bin_tiles > chunk_hist.n) {
             drain();  // resize: wait for queued frames that still use the old buffers
             ranges.ensure(2 * nt);
@@ -461,10 +462,11 @@ struct gs_renderer {
             for (int k = 0; k < pending; ++k) {
                 FrameSlot& q = slots[(frames_enqueued - pending + k) % kMaxInFlight];
                 redo.push_back({q.u, q.rgba, q.bgra});
-                need = std::max<uint64_t>(need, q.h_counters->instances);
+                // D instances, or 4 x E1 level-1 candidates (the chunk table is sized from the capacity)
+                need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, 4ull * q.h_counters->bin_entries));
             }
             need = need + need / 8 + 4096;
-            if (need > 0xFFFFF000ull) throw Error(GS_ERR_OVERFLOW, "more than 2^32 tile instances");
+            if (need > kMaxInstances) throw Error(GS_ERR_OVERFLOW, "more than 2^30 tile instances");
             if (retries > 64) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
             frames_enqueued -= pending;
             pending = 0;

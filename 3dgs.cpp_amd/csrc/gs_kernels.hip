@@ -757,8 +757,8 @@ struct BinArgs {
     uint32_t max_chunks;
 };
 
-constexpr int kBinChunk = 256;    // candidates per chunk (= one workgroup)
-constexpr int kBinGrid = 2048;    // persistent grid striding over the (device-resident) chunk count
+constexpr int kBinChunk = 64;     // candidates per chunk (= one wave; the four waves of a workgroup are independent)
+constexpr int kBinGrid = 2048;    // persistent grid (x4 waves) striding over the device-resident chunk count
 
 // Offsets and chunk prefixes of all bins (once per block); returns the total number of chunks.
 __device__ __forceinline__ uint32_t bin_prepare(const BinArgs& a, uint32_t* s_off, uint32_t* s_cpre, uint32_t* scratch) {
@@ -771,7 +771,7 @@ __device__ __forceinline__ uint32_t bin_prepare(const BinArgs& a, uint32_t* s_of
     s_off[tid] = off;
     s_cpre[tid] = cpre;
     __syncthreads();
-    return total_chunks;
+    return __builtin_amdgcn_readfirstlane(total_chunks);  // same in every lane: keep it scalar
 }
 
 // chunk id -> (bin, first candidate, candidate count); uniform binary search over the 256 chunk prefixes
@@ -821,25 +821,35 @@ __device__ __forceinline__ void bin_cover_masks(int shift, int lx0, int ly0, int
     }
 }
 
-// Per-wave walk over its 64 candidates with lanes transposed onto tiles: for candidate i the coverage word is
-// broadcast (v_readlane) and used directly as the lane predicate (inverse ballot), so "append candidate i to
-// the lists of the tiles it covers, in order" costs a handful of instructions and needs no ranking at all --
-// each lane just advances the cursor of the tile(s) it owns.  FILL = false only counts.
+// Per-wave walk over its 64 candidates with lanes transposed onto tiles: candidate i's coverage word is
+// broadcast through a wave-private LDS slab (same-address read) and every lane tests its own bit in the VALU
+// (no exec-mask juggling, no SGPR round trips: the walk is otherwise bound by the CU's scalar unit and by
+// v_readlane hazards); "append candidate i to the lists of the tiles it covers, in order"
+// is then `store id at cursor; cursor += hit`.  The store is a raw buffer store whose offset is forced out of
+// range on lanes that miss, so the hardware's bounds check drops it (and enforces the list capacity) without a
+// branch.  FILL = false only counts.
 template <int R, bool FILL>
 __device__ __forceinline__ void bin_walk(const uint64_t (&m)[R], uint32_t g, uint32_t (&cursor)[R], uint32_t nvalid,
-                                         uint32_t* __restrict__ out, uint32_t capacity) {
-    for (uint32_t i = 0; i < nvalid; ++i) {
-        const uint32_t gi = __builtin_amdgcn_readlane(g, i);
+                                         __amdgpu_buffer_rsrc_t out, uint64_t* __restrict__ slab /* wave-private [64][R] */) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t bit_lo = lane < 32 ? (1u << lane) : 0u, bit_hi = lane >= 32 ? (1u << (lane - 32)) : 0u;
+    uint32_t present = 0;  // which of the R words are non-zero for this lane's candidate
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        present |= (m[r] != 0 ? 1u : 0u) << r;
+        slab[lane * R + r] = m[r];  // broadcast source: same-address LDS reads, results stay in VGPRs
+    }
+    const uint32_t n = __builtin_amdgcn_readfirstlane(nvalid);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t gi = FILL ? __builtin_amdgcn_readlane(g, i) : 0u;
+        const uint32_t pres = R > 1 ? __builtin_amdgcn_readlane(present, i) : 1u;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m[r], i);
-            const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m[r] >> 32), i);
-            const uint64_t cm = ((uint64_t)hi << 32) | lo;
-            if (cm == 0) continue;  // uniform
-            if (__builtin_amdgcn_inverse_ballot_w64(cm)) {
-                if (FILL && cursor[r] < capacity) out[cursor[r]] = gi;
-                cursor[r] += 1;
-            }
+            if (R > 1 && !((pres >> r) & 1u)) continue;  // uniform: most candidates touch one or two words
+            const uint64_t cm = slab[i * R + r];
+            const bool hit = (((uint32_t)cm & bit_lo) | ((uint32_t)(cm >> 32) & bit_hi)) != 0;
+            if (FILL) __builtin_amdgcn_raw_buffer_store_b32(gi, out, hit ? cursor[r] * 4u : 0xFFFFFFFFu, 0, 0);
+            cursor[r] += hit ? 1u : 0u;
         }
     }
 }
@@ -847,39 +857,44 @@ __device__ __forceinline__ void bin_walk(const uint64_t (&m)[R], uint32_t g, uin
 template <int R>
 __global__ __launch_bounds__(BLOCK) void k_bin_count(BinArgs a) {
     __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
-    __shared__ uint32_t s_wcnt[4][64 * R];
-    const uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
+    __shared__ uint64_t s_slab[4][64 * R];
+    uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     constexpr int SS = 64 * R;
-    for (uint32_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+    if (total_chunks > a.max_chunks) {  // chunk table too small: flag, stay in bounds; the frame is re-run
+        if (blockIdx.x == 0 && tid == 0) a.counters->overflow = 1;
+        total_chunks = a.max_chunks;
+    }
+    // the chunk loop is per wave: tell the compiler its control values are wave-uniform (scalar registers)
+    const uint32_t wu = __builtin_amdgcn_readfirstlane((uint32_t)w);
+    for (uint32_t chunk = blockIdx.x * 4 + wu; chunk < total_chunks; chunk += gridDim.x * 4) {
         uint32_t bin, first, count;
         bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
-        const bool have = (uint32_t)tid < count;
+        bin = __builtin_amdgcn_readfirstlane(bin);
+        first = __builtin_amdgcn_readfirstlane(first);
+        count = __builtin_amdgcn_readfirstlane(count);
         uint64_t m[R];
         uint32_t g = 0;
         int lx0 = 0, ly0 = 0, lx1 = 0, ly1 = 0;
-        if (have) {
-            g = a.cand[first + tid];
+        if ((uint32_t)lane < count) {
+            g = a.cand[first + lane];
             bin_local_box(a, bin, a.aabb[g], lx0, ly0, lx1, ly1);
         }
         bin_cover_masks<R>(a.shift, lx0, ly0, lx1, ly1, m);
         uint32_t cursor[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) cursor[r] = 0;
-        const uint32_t nvalid = count > (uint32_t)w * WAVE ? min((uint32_t)WAVE, count - w * WAVE) : 0;
-        bin_walk<R, false>(m, g, cursor, nvalid, nullptr, 0);
-        __syncthreads();  // previous chunk's totals have been read
-#pragma unroll
-        for (int r = 0; r < R; ++r) s_wcnt[w][r * 64 + lane] = cursor[r];
-        __syncthreads();
+        bin_walk<R, false>(m, g, cursor, count, __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, 0, 0x27000), s_slab[w]);
         uint32_t* out = a.chunk_hist + (size_t)chunk * SS;
-        for (int t = tid; t < SS; t += BLOCK) out[t] = s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t];
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[r * 64 + lane] = cursor[r];
     }
 }
 
 // One block per bin: for each of its tiles, exclusive prefix of the chunk counts (in place) and the tile total.
 __global__ __launch_bounds__(BLOCK) void k_bin_scan(BinArgs a) {
     __shared__ uint32_t scratch[8];
+    __shared__ uint32_t s_seg[4][64];
     const int tid = threadIdx.x, S = 1 << a.shift, SS = S * S;
     const uint32_t bin = blockIdx.x;
     const uint32_t c = a.bin_count[tid];
@@ -892,29 +907,59 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scan(BinArgs a) {
         s_n = nch;
     }
     __syncthreads();
-    const uint32_t first = s_first, n = s_n;
+    const uint32_t first = min(s_first, a.max_chunks), n = min(s_n, a.max_chunks - first);
     const uint32_t ox = (bin % a.bins_x) << a.shift, oy = (bin / a.bins_x) << a.shift;
-    for (int t = tid; t < SS; t += BLOCK) {
+    // 64-tile bins: four threads per tile, each sweeping a quarter of the bin's chunks (sum, then prefix);
+    // larger bins: one thread per tile (strided), one sweep
+    const int P = SS == 64 ? 4 : 1;
+    for (int t0 = 0; t0 < SS; t0 += BLOCK / P) {
+        const int t = t0 + (P == 4 ? (tid & 63) : tid);
+        const int seg = P == 4 ? (tid >> 6) : 0;
+        const bool on = t < SS;
+        const uint32_t q0 = (uint32_t)((uint64_t)n * seg / P), q1 = (uint32_t)((uint64_t)n * (seg + 1) / P);
+        uint32_t* base = a.chunk_hist + (size_t)first * SS + (on ? t : 0);
+        uint32_t seg_sum = 0;
+        if (P == 4) {
+            if (on) {
+                uint32_t q = q0;
+                for (; q + 8 <= q1; q += 8) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(q + k) * SS];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) seg_sum += v[k];
+                }
+                for (; q < q1; ++q) seg_sum += base[(size_t)q * SS];
+            }
+            s_seg[seg][tid & 63] = seg_sum;
+            __syncthreads();
+        }
         uint32_t running = 0;
-        uint32_t* p = a.chunk_hist + (size_t)first * SS + t;
-        uint32_t q = 0;
-        for (; q + 8 <= n; q += 8, p += 8 * (size_t)SS) {  // 8 independent loads in flight per step
-            uint32_t v[8];
+        if (P == 4)
+            for (int k = 0; k < seg; ++k) running += s_seg[k][tid & 63];
+        if (on) {
+            uint32_t q = q0;
+            for (; q + 8 <= q1; q += 8) {  // 8 independent loads in flight per step
+                uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)k * SS];
+                for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(q + k) * SS];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                p[(size_t)k * SS] = running;
-                running += v[k];
+                for (int k = 0; k < 8; ++k) {
+                    base[(size_t)(q + k) * SS] = running;
+                    running += v[k];
+                }
+            }
+            for (; q < q1; ++q) {
+                const uint32_t v = base[(size_t)q * SS];
+                base[(size_t)q * SS] = running;
+                running += v;
+            }
+            if (seg == P - 1) {
+                const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
+                if (x < a.tiles_x && y < a.tiles_y) a.tile_total[y * a.tiles_x + x] = running;
             }
         }
-        for (; q < n; ++q, p += SS) {
-            const uint32_t v = *p;
-            *p = running;
-            running += v;
-        }
-        const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
-        if (x < a.tiles_x && y < a.tiles_y) a.tile_total[y * a.tiles_x + x] = running;
+        if (P == 4) __syncthreads();
     }
 }
 
@@ -954,47 +999,40 @@ __global__ __launch_bounds__(1024) void k_tile_scan(BinArgs a) {
 template <int R>
 __global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
     __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
-    __shared__ uint32_t s_wcnt[4][64 * R];
-    const uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
+    __shared__ uint64_t s_slab[4][64 * R];
+    const uint32_t total_chunks = min(bin_prepare(a, s_off, s_cpre, scratch), a.max_chunks);
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     constexpr int SS = 64 * R;
     const int S = 1 << a.shift;
-    for (uint32_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+    // raw buffer over the list: byte offsets >= 4 * capacity are dropped by the hardware bounds check
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, a.capacity * 4u, 0x27000);
+    // the chunk loop is per wave: tell the compiler its control values are wave-uniform (scalar registers)
+    const uint32_t wu = __builtin_amdgcn_readfirstlane((uint32_t)w);
+    for (uint32_t chunk = blockIdx.x * 4 + wu; chunk < total_chunks; chunk += gridDim.x * 4) {
         uint32_t bin, first, count;
         bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
-        const bool have = (uint32_t)tid < count;
+        bin = __builtin_amdgcn_readfirstlane(bin);
+        first = __builtin_amdgcn_readfirstlane(first);
+        count = __builtin_amdgcn_readfirstlane(count);
         uint64_t m[R];
         uint32_t g = 0;
         int lx0 = 0, ly0 = 0, lx1 = 0, ly1 = 0;
-        if (have) {
-            g = a.cand[first + tid];
+        if ((uint32_t)lane < count) {
+            g = a.cand[first + lane];
             bin_local_box(a, bin, a.aabb[g], lx0, ly0, lx1, ly1);
         }
         bin_cover_masks<R>(a.shift, lx0, ly0, lx1, ly1, m);
-        const uint32_t nvalid = count > (uint32_t)w * WAVE ? min((uint32_t)WAVE, count - w * WAVE) : 0;
-        // pass 1: how many of this wave's candidates land in each tile
-        uint32_t cursor[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) cursor[r] = 0;
-        bin_walk<R, false>(m, g, cursor, nvalid, nullptr, 0);
-        __syncthreads();  // previous chunk's counts have been read
-#pragma unroll
-        for (int r = 0; r < R; ++r) s_wcnt[w][r * 64 + lane] = cursor[r];
-        __syncthreads();
-        // start of this wave's run in each tile's list: range start + earlier chunks + earlier waves
+        // where this chunk's run starts in each tile's list: range start + earlier chunks of the bin
         const uint32_t ox = (bin % a.bins_x) << a.shift, oy = (bin / a.bins_x) << a.shift;
         const uint32_t* prefix = a.chunk_hist + (size_t)chunk * SS;
+        uint32_t cursor[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int t = r * 64 + lane;
             const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
-            uint32_t base = 0;
-            if (x < a.tiles_x && y < a.tiles_y) base = a.ranges[2 * (y * a.tiles_x + x)] + prefix[t];
-            for (int k = 0; k < w; ++k) base += s_wcnt[k][t];
-            cursor[r] = base;
+            cursor[r] = (x < a.tiles_x && y < a.tiles_y) ? a.ranges[2 * (y * a.tiles_x + x)] + prefix[t] : 0u;
         }
-        // pass 2: append, in candidate order
-        bin_walk<R, true>(m, g, cursor, nvalid, a.sorted_gid, a.capacity);
+        bin_walk<R, true>(m, g, cursor, count, out, s_slab[w]);  // append, in candidate order
     }
 }
 
