@@ -83,3 +83,81 @@ def test_instance_overflow_regrows(pkg, oracle, gpu):
     assert st.num_instances > (1 << 20) and st.retries >= 1
     assert np.abs(img - ref["image"]).max() <= PIXEL_TOL
     np.testing.assert_array_equal(rend.stage("sorted_gid"), ref["sorted_payload"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 2047, 2048, 2049, 4097])
+def test_small_counts_around_wave_and_tile_boundaries(pkg, oracle, gpu, n):
+    """Visible counts around the wave (64) and radix-tile (2048) sizes, where ranking / chunking code changes regime."""
+    rec = pkg.synth.synth_records(n, seed=100 + n, kind="A")
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, 160, 96)
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+
+
+def test_degenerate_keys(pkg, oracle, gpu):
+    """All Gaussians at one depth (every radix digit constant, ties broken by id) and coincident Gaussians."""
+    rec = pkg.synth.synth_records(5000, seed=8, kind="A")
+    rec[:, 2] = -4.0          # identical view depth for the default camera
+    rec[2500:, 0:3] = rec[:2500, 0:3]  # pairs of coincident centres
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, 256, 144)
+    assert len(np.unique(rend.stage("depth")[rend.stage("tiles") > 0])) == 1
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+
+
+def test_one_dense_bin(pkg, oracle, gpu):
+    """Thousands of splats inside one 128x128-pixel bin: long chunk lists in a single bin, empty bins elsewhere."""
+    rec = pkg.synth.synth_records(20000, seed=9, kind="A")
+    rec[:, 0] = rec[:, 0] * 0.02 + 0.3
+    rec[:, 1] = rec[:, 1] * 0.02 - 0.2
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, 1280, 720)
+    compare_stages(pkg, rend, u, ref)
+    assert rend.stats().num_bin_entries >= rend.stats().num_visible
+    assert np.abs(img - ref["image"]).max() <= PIXEL_TOL
+
+
+class _HipBuffers:
+    """Device allocations through the HIP runtime the library itself uses (no torch: its bundled runtime and
+    the system one cannot both own the GPU in one process when the library initialises first)."""
+
+    def __init__(self):
+        import ctypes
+        self.C = ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.ptrs = []
+
+    def alloc(self, nbytes):
+        p = self.C.c_void_p()
+        assert self.hip.hipMalloc(self.C.byref(p), self.C.c_size_t(nbytes)) == 0
+        self.ptrs.append(p)
+        return p.value
+
+    def download(self, ptr, shape, dtype):
+        out = np.zeros(shape, dtype)
+        assert self.hip.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), self.C.c_void_p(ptr), self.C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def close(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+
+
+def test_frames_in_flight_match_serial(pkg, oracle, gpu):
+    """Eight queued frames on four streams (different poses, distinct targets) == the same poses one at a time."""
+    rec = pkg.synth.synth_records(30000, seed=10, kind="A")
+    w, h = 640, 360
+    scene = pkg.Scene.from_records(rec, device=0)
+    rend = pkg.Renderer(scene)
+    poses = [pkg.camera_uniforms(pkg.make_camera(rotation=pkg.dist.pose_quaternion(k, 2.0)), w, h) for k in range(8)]
+    serial = [rend.render_host(u)[0] for u in poses]
+    rend.set_frames_in_flight(4)
+    dev = _HipBuffers()
+    outs = [dev.alloc(w * h * 16) for _ in poses]
+    for u, o in zip(poses, outs):
+        rend.render(u, o, 0)
+    rend.synchronize()
+    for s_img, o in zip(serial, outs):
+        np.testing.assert_array_equal(dev.download(o, (h, w, 4), np.float32), s_img)
+    dev.close()
+    ref = oracle.stages(oracle.activate_records(rec), poses[3].view(oracle.UNIFORMS_DT))["image"]
+    assert np.abs(serial[3] - ref).max() <= PIXEL_TOL
