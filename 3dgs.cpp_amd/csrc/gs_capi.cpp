@@ -16,6 +16,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gs_host_math.h"
@@ -116,19 +117,37 @@ namespace {
 constexpr uint64_t kMaxGaussians = 1ull << 31;  // ids and counts are 32-bit on the device
 constexpr uint64_t kMaxInstances = (1ull << 30) - 4096;  // the per-tile lists live in one 4 GiB raw buffer
 
+// Load-time host work (activation, AoS -> blob, PLY remapping) is embarrassingly parallel over Gaussians; the
+// reference does it on one thread, one 248-byte ifstream::read per Gaussian (GSScene.cpp:36-59).
+template <class F>
+void parallel_for(uint64_t n, F&& body) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t workers = std::min<uint64_t>(std::min(16u, hw), std::max<uint64_t>(1, n / 16384));
+    if (workers <= 1) {
+        body(uint64_t{0}, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (uint64_t w = 0; w < workers; ++w)
+        pool.emplace_back([&, w] { body(n * w / workers, n * (w + 1) / workers); });
+    for (auto& t : pool) t.join();
+}
+
 void upload_vertices(gs_scene* s, const float* vertices, uint64_t n) {
     // AoS GSScene::Vertex[n] -> blob: 11 SoA planes (pos3, scale3, rot4, opacity) + AoS SH block (48 per Gaussian)
     if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
     s->n = n;
     std::vector<float> planes(static_cast<size_t>(gs::P_COUNT) * n);
-    for (uint64_t i = 0; i < n; ++i) {
-        const float* v = vertices + i * gs::host::kVertexFloats;
-        for (int k = 0; k < 3; ++k) planes[(gs::P_POS + k) * n + i] = v[k];
-        for (int k = 0; k < 3; ++k) planes[(gs::P_SCALE + k) * n + i] = v[4 + k];
-        for (int k = 0; k < 4; ++k) planes[(gs::P_ROT + k) * n + i] = v[8 + k];
-        planes[static_cast<size_t>(gs::P_OPACITY) * n + i] = v[7];
-        for (int k = 0; k < 48; ++k) planes[static_cast<size_t>(gs::P_SH) * n + i * 48 + k] = v[12 + k];
-    }
+    parallel_for(n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i) {
+            const float* v = vertices + i * gs::host::kVertexFloats;
+            for (int k = 0; k < 3; ++k) planes[(gs::P_POS + k) * n + i] = v[k];
+            for (int k = 0; k < 3; ++k) planes[(gs::P_SCALE + k) * n + i] = v[4 + k];
+            for (int k = 0; k < 4; ++k) planes[(gs::P_ROT + k) * n + i] = v[8 + k];
+            planes[static_cast<size_t>(gs::P_OPACITY) * n + i] = v[7];
+            std::memcpy(&planes[static_cast<size_t>(gs::P_SH) * n + i * 48], v + 12, 48 * sizeof(float));
+        }
+    });
     s->owned_blob.alloc(planes.size());
     s->blob = s->owned_blob.p;
     if (n) HIP_CHECK(hipMemcpy(s->blob, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -137,25 +156,58 @@ void upload_vertices(gs_scene* s, const float* vertices, uint64_t n) {
 
 void activate_and_upload(gs_scene* s, const float* records, uint64_t n) {
     std::vector<float> verts(static_cast<size_t>(n) * gs::host::kVertexFloats);
-    for (uint64_t i = 0; i < n; ++i)
-        gs::host::activate_record(records + i * gs::host::kRecordFloats, verts.data() + i * gs::host::kVertexFloats);
+    parallel_for(n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i)
+            gs::host::activate_record(records + i * gs::host::kRecordFloats, verts.data() + i * gs::host::kVertexFloats);
+    });
     upload_vertices(s, verts.data(), n);
 }
 
-// GSScene::loadPlyHeader, GSScene.cpp:99-149: format, element vertex N, end_header.
+// PLY ingest.  The reference (GSScene::loadPlyHeader, GSScene.cpp:99-149) reads only `format`, `element vertex N`
+// and `end_header`, never checks property names and assumes 62 floats per vertex in the INRIA order.  That exact
+// layout takes the same path here (bit-identical records).  Any other binary-little-endian layout is mapped BY
+// NAME instead of being silently mis-read: properties may come in any order, extra ones are skipped, normals are
+// optional, and a lower SH degree (3*K f_rest values, K = 0, 3, 8 or 15 per channel, planar) is zero-extended.
+struct PlyProperty {
+    std::string type, name;
+    size_t offset = 0, size = 0;
+};
+
+size_t ply_type_size(const std::string& t) {
+    if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+    if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+    if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+    if (t == "double" || t == "float64") return 8;
+    return 0;
+}
+
 std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
     std::ifstream f(path, std::ios::binary);
     if (!f.is_open()) throw Error(GS_ERR_IO, "File does not exist: " + path);
-    std::string line;
+    std::string line, format;
     long long n = -1;
-    bool header_end = false;
+    bool header_end = false, in_vertex = false;
+    std::vector<PlyProperty> props;
+    size_t stride = 0;
     while (std::getline(f, line)) {
         std::istringstream iss(line);
         std::string token;
         iss >> token;
-        if (token == "element") {
+        if (token == "format") {
+            iss >> format;
+        } else if (token == "element") {
             iss >> token;
-            if (token == "vertex") iss >> n;
+            in_vertex = token == "vertex";
+            if (in_vertex) iss >> n;
+        } else if (token == "property" && in_vertex) {
+            PlyProperty p;
+            iss >> p.type >> p.name;
+            if (p.type == "list") throw Error(GS_ERR_IO, "PLY vertex element has a list property: " + path);
+            p.size = ply_type_size(p.type);
+            if (!p.size) throw Error(GS_ERR_IO, "PLY property '" + p.name + "' has unknown type '" + p.type + "'");
+            p.offset = stride;
+            stride += p.size;
+            props.push_back(p);
         } else if (token == "end_header") {
             header_end = true;
             break;
@@ -163,11 +215,73 @@ std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
     }
     if (!header_end) throw Error(GS_ERR_IO, "Could not find end of header");
     if (n < 0) throw Error(GS_ERR_IO, "PLY header has no 'element vertex'");
+    if (!format.empty() && format != "binary_little_endian")
+        throw Error(GS_ERR_IO, "unsupported PLY format '" + format + "' (binary_little_endian only): " + path);
+
+    static const char* const kStandard[] = {"x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"};
+    bool standard = props.size() == gs::host::kRecordFloats || props.empty();
+    for (size_t k = 0; standard && k < props.size(); ++k) {
+        std::string want;
+        if (k < 9) want = kStandard[k];
+        else if (k < 54) want = "f_rest_" + std::to_string(k - 9);
+        else if (k == 54) want = "opacity";
+        else if (k < 58) want = "scale_" + std::to_string(k - 55);
+        else want = "rot_" + std::to_string(k - 58);
+        standard = props[k].size == 4 && props[k].name == want && (props[k].type == "float" || props[k].type == "float32");
+    }
     std::vector<float> rec(static_cast<size_t>(n) * gs::host::kRecordFloats);
-    f.read(reinterpret_cast<char*>(rec.data()), static_cast<std::streamsize>(rec.size() * sizeof(float)));
-    if (static_cast<size_t>(f.gcount()) != rec.size() * sizeof(float))
-        throw Error(GS_ERR_IO, "PLY payload is shorter than 'element vertex' x 62 floats: " + path);
     *n_out = static_cast<uint64_t>(n);
+    if (standard) {  // the reference's layout (or a header without property lines, which the reference also accepts)
+        f.read(reinterpret_cast<char*>(rec.data()), static_cast<std::streamsize>(rec.size() * sizeof(float)));
+        if (static_cast<size_t>(f.gcount()) != rec.size() * sizeof(float))
+            throw Error(GS_ERR_IO, "PLY payload is shorter than 'element vertex' x 62 floats: " + path);
+        return rec;
+    }
+
+    // name-mapped path: slot k of the 62-float record <- byte offset in the file's vertex record (or absent)
+    std::vector<long> src(gs::host::kRecordFloats, -1);
+    auto find = [&](const std::string& name) -> long {
+        for (const auto& p : props)
+            if (p.name == name) {
+                if (p.size != 4 || !(p.type == "float" || p.type == "float32"))
+                    throw Error(GS_ERR_IO, "PLY property '" + name + "' must be a 32-bit float");
+                return static_cast<long>(p.offset);
+            }
+        return -1;
+    };
+    auto require = [&](int slot, const std::string& name) {
+        src[slot] = find(name);
+        if (src[slot] < 0) throw Error(GS_ERR_IO, "PLY is missing property '" + name + "': " + path);
+    };
+    require(0, "x");
+    require(1, "y");
+    require(2, "z");
+    for (int k = 0; k < 3; ++k) require(6 + k, "f_dc_" + std::to_string(k));
+    require(54, "opacity");
+    for (int k = 0; k < 3; ++k) require(55 + k, "scale_" + std::to_string(k));
+    for (int k = 0; k < 4; ++k) require(58 + k, "rot_" + std::to_string(k));
+    int rest = 0;
+    while (rest < 45 && find("f_rest_" + std::to_string(rest)) >= 0) ++rest;
+    if (rest % 3 != 0) throw Error(GS_ERR_IO, "PLY has " + std::to_string(rest) + " f_rest properties (must be a multiple of 3)");
+    const int per_channel = rest / 3;  // planar: all R, then all G, then all B
+    for (int c = 0; c < 3; ++c)
+        for (int j = 0; j < per_channel; ++j) src[9 + c * 15 + j] = find("f_rest_" + std::to_string(c * per_channel + j));
+
+    std::vector<char> raw(static_cast<size_t>(n) * stride);
+    f.read(raw.data(), static_cast<std::streamsize>(raw.size()));
+    if (static_cast<size_t>(f.gcount()) != raw.size())
+        throw Error(GS_ERR_IO, "PLY payload is shorter than 'element vertex' x record size: " + path);
+    parallel_for(static_cast<uint64_t>(n), [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i) {
+            const char* in = raw.data() + i * stride;
+            float* out = rec.data() + i * gs::host::kRecordFloats;
+            for (int k = 0; k < gs::host::kRecordFloats; ++k) {
+                float v = 0.0f;  // absent: normals, higher-degree SH
+                if (src[k] >= 0) std::memcpy(&v, in + src[k], sizeof v);
+                out[k] = v;
+            }
+        }
+    });
     return rec;
 }
 
@@ -532,8 +646,10 @@ int gs_device_count(int* count) {
 int gs_activate_records(const float* records, uint64_t n, float* vertices) {
     return guarded([&] {
         if ((!records || !vertices) && n) throw Error(GS_ERR_INVALID, "null argument");
-        for (uint64_t i = 0; i < n; ++i)
-            gs::host::activate_record(records + i * gs::host::kRecordFloats, vertices + i * gs::host::kVertexFloats);
+        parallel_for(n, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi; ++i)
+                gs::host::activate_record(records + i * gs::host::kRecordFloats, vertices + i * gs::host::kVertexFloats);
+        });
     });
 }
 

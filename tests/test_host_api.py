@@ -113,3 +113,76 @@ def test_synth_scene_is_deterministic_and_sliceable(pkg):
     np.testing.assert_array_equal(a[300:700], b)
     assert not a[:, 3:6].any()  # normals are zero (GSScene.cpp:56-58)
     assert abs(float(a[:, 55:58].mean()) - (-4.5 - np.log(4000 / 1e6) / 3)) < 0.05
+
+
+def _write_custom_ply(path, names_types, rows):
+    """rows: dict name -> array; writes a binary little-endian PLY with the given property order/types."""
+    n = len(next(iter(rows.values())))
+    dt = np.dtype([(nm, {"float": "<f4", "double": "<f8", "uchar": "u1", "int": "<i4"}[ty]) for nm, ty in names_types])
+    data = np.zeros(n, dt)
+    for nm, _ in names_types:
+        data[nm] = rows[nm]
+    header = "ply\nformat binary_little_endian 1.0\ncomment test\nelement vertex %d\n" % n
+    header += "".join(f"property {ty} {nm}\n" for nm, ty in names_types) + "end_header\n"
+    with open(path, "wb") as f:
+        f.write(header.encode())
+        f.write(data.tobytes())
+
+
+def test_ply_name_mapped_layouts(pkg, tmp_path):
+    """Beyond the reference (which silently mis-reads anything but the 62-float INRIA order): properties in any
+    order, extra / missing-normal properties, lower SH degree -- mapped by name, zero-extended."""
+    rec = pkg.synth.synth_records(300, seed=31, kind="A")
+    std_names = pkg.synth._PROPS
+    cols = {nm: rec[:, k].copy() for k, nm in enumerate(std_names)}
+    # (1) shuffled order, no normals, an extra uchar and an extra double property
+    order = [nm for nm in std_names if nm not in ("nx", "ny", "nz")]
+    rng = np.random.default_rng(5)
+    rng.shuffle(order)
+    layout = [(nm, "float") for nm in order]
+    layout.insert(3, ("label", "uchar"))
+    layout.insert(20, ("confidence", "double"))
+    cols["label"] = np.arange(300) % 7
+    cols["confidence"] = np.linspace(0, 1, 300)
+    p1 = str(tmp_path / "shuffled.ply")
+    _write_custom_ply(p1, layout, cols)
+    np.testing.assert_array_equal(pkg.read_ply(p1), rec)
+    # (2) SH degree 1: 9 f_rest values (3 per channel, planar) -> zero-extended to degree 3
+    K = 3
+    deg1 = [(nm, "float") for nm in std_names if not nm.startswith("f_rest_")]
+    deg1 += [(f"f_rest_{i}", "float") for i in range(3 * K)]
+    cols1 = dict(cols)
+    for c in range(3):
+        for j in range(K):
+            cols1[f"f_rest_{c * K + j}"] = rec[:, 9 + c * 15 + j]
+    p2 = str(tmp_path / "deg1.ply")
+    _write_custom_ply(p2, deg1, cols1)
+    expect = rec.copy()
+    for c in range(3):
+        expect[:, 9 + c * 15 + K: 9 + (c + 1) * 15] = 0
+    np.testing.assert_array_equal(pkg.read_ply(p2), expect)
+    # (3) errors: missing required property, non-float required property, ascii format
+    p3 = str(tmp_path / "noopacity.ply")
+    _write_custom_ply(p3, [(nm, "float") for nm in std_names if nm != "opacity"], cols)
+    with pytest.raises(pkg.GsError) as e:
+        pkg.read_ply(p3)
+    assert e.value.code == -2 and "opacity" in str(e.value)
+    p4 = str(tmp_path / "doublex.ply")
+    _write_custom_ply(p4, [(nm, "double" if nm == "x" else "float") for nm in std_names], cols)
+    with pytest.raises(pkg.GsError) as e:
+        pkg.read_ply(p4)
+    assert "32-bit float" in str(e.value)
+    p5 = tmp_path / "ascii.ply"
+    p5.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")
+    with pytest.raises(pkg.GsError) as e:
+        pkg.read_ply(str(p5))
+    assert "unsupported PLY format" in str(e.value)
+
+
+def test_parallel_activation_matches_serial(pkg, oracle):
+    """Load-time activation runs on several host threads for large scenes; results must not depend on that."""
+    rec = pkg.synth.synth_records(200_000, seed=6, kind="S")
+    a = pkg.activate_records(rec)
+    b = np.concatenate([pkg.activate_records(rec[i:i + 10_000]) for i in range(0, len(rec), 10_000)])
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    np.testing.assert_array_equal(a[:2000].view(np.uint32), oracle.activate_records(rec[:2000]).view(np.float32).reshape(-1, 60).view(np.uint32))
