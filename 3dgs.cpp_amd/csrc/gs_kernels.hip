@@ -1165,13 +1165,20 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     __shared__ float4 s_rec[4][WAVE][4];  // {c00 c01 c11 o} {u v r g} {b, pmin, -, -} {pad}: 64-byte stride
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const uint32_t qx0 = blockIdx.x * kTile + (w & 1) * 8, qy0 = blockIdx.y * kTile + (w >> 1) * 8;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed only), and each
+    // XCD has a private 4 MiB L2.  Give every XCD one contiguous band of tiles so that the splat records its
+    // tiles gather (neighbouring tiles share most of them) stay in that XCD's L2.  Bijective for any tile count.
+    const uint32_t nb = gridDim.x, bq = nb / 8, br = nb % 8;
+    const uint32_t xcd = blockIdx.x % 8, bi = blockIdx.x / 8;
+    const uint32_t tile = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+    const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const uint32_t qx0 = tile_x * kTile + (w & 1) * 8, qy0 = tile_y * kTile + (w >> 1) * 8;
     const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < width && py < height;  // render.comp:36-39
     const float fx = (float)px, fy = (float)py;
     const float rx0 = (float)qx0, ry0 = (float)qy0;
 
-    const uint2 range = ranges[blockIdx.x + blockIdx.y * tiles_x];
+    const uint2 range = ranges[tile];
     float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     // Pixel predicates live in 64-bit scalar masks (one bit per lane): combining them is scalar-unit work
     // and testing "any lane" is one s_cmp, where bool-typed code would spend VALU instructions on it.
@@ -1271,7 +1278,7 @@ void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const Attr
                   uint32_t height, float* rgba, uint8_t* bgra, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_blend, dim3(tx, ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
+    hipLaunchKernelGGL(k_blend, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                        sorted_gid, av.conic_op, av.uv_rg, av.b, width, height, tx,
                        reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra));
 }
