@@ -181,9 +181,11 @@ def main():
             "roofline": {"kernel": {"render": "k_blend"}.get(dom, dom), "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, n, w, h),
-                         "note": "blend is FP32-VALU bound, not HBM bound (DESIGN.md §5); frac is the HBM view"},
+                         "note": "k_blend is FP32-VALU bound, not HBM bound (DESIGN.md §4): frac is its HBM view; "
+                                 "valu = its share of the measured wave64 VALU issue rate",
+                         "valu": valu_view(dom, n, w, h, ms[dom])},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(n, w, h)
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -202,6 +204,23 @@ def pmc_traffic(pass_name, n, w, h):
             return None
         k = prof["kernels"][{"render": "k_blend", "preprocess": "k_preprocess"}[pass_name]]
         return int((k["fetch_kb"] * k.get("fetch_scale", 1.0) + k["write_kb"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def valu_view(pass_name, n, w, h, ms):
+    """The binding roof of the blend: VALU wave-instructions per launch (SQ_INSTS_VALU of the committed PMC run)
+    against the issue rate measured by tools/ubench/valu_rate.hip (one wave64 fp32 instruction per 1.09 ns per SIMD,
+    1024 SIMDs)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            prof = json.load(f)
+        if [prof["gaussians"], prof["width"], prof["height"]] != [n, w, h] or pass_name != "render":
+            return None
+        insts = prof["kernels"]["k_blend"]["valu_wave_insts"]
+        peak = 1024 / 1.09e-9
+        return {"wave_insts": insts, "achieved_per_s": round(insts / (ms * 1e-3), 3), "peak_per_s": round(peak, 3),
+                "frac": round(insts / (ms * 1e-3) / peak, 4)}
     except (OSError, KeyError, ValueError):
         return None
 
