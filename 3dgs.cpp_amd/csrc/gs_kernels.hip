@@ -1208,7 +1208,8 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
             }
             // classify entry `lane` of this chunk against the wave's quadrant
             const float tau = __logf(255.0f * cur.co.w);
-            const float lim = fmaxf(tau, 0.0f) * 1.001f + 1e-3f;
+            // NaN opacity: min(0.99, NaN) is 0.99 in the pipeline's definition -> the entry is never culled
+            const float lim = tau == tau ? fmaxf(tau, 0.0f) * 1.001f + 1e-3f : 3.0e38f;
             bool keep = have && !(tau <= -1e-3f);  // tau <= 0: o*exp(p) < 1/255 for every p <= 0
             if (keep) {
                 const float mq = min_q_rect(cur.co.x, cur.co.y, cur.co.z, cur.uv.x, cur.uv.y, rx0, rx0 + 7.0f,
@@ -1237,7 +1238,8 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                 // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
                 const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);        // FMA
                 const float power = __builtin_fmaf(-(co.y * dx), dy, -0.5f * s);      // FMA
-                const uint64_t m1 = alive & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+                // power <= 0 is false for NaN: a NaN power skips the entry (the pipeline's definition)
+                const uint64_t m1 = alive & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                     __builtin_amdgcn_ballot_w64(!(power < bp.y));
                 if (m1 != 0) {
                     STAT_ADD(4, 1);                   // pairs reaching exp

@@ -634,7 +634,10 @@ void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const u
                          * multiply-adds GLSL allows a compiler to contract written as FMAs */
                         float s = fmaf(co[2] * dy, dy, co[0] * dx * dx);
                         float power = fmaf(-(co[1] * dx), dy, -0.5f * s);
-                        if (power > 0.0f) continue;
+                        /* :68.  A NaN power (non-finite conic or centre) also skips: GLSL leaves
+                         * the comparison and the following exp(NaN) undefined; the pipeline
+                         * defines "no contribution". */
+                        if (power > 0.0f || power != power) continue;
                         float alpha = fminf(0.99f, co[3] * gso_exp(power)); /* :77 */
                         if (alpha < 1.0f / 255.0f) continue;
                         float test_T = T * (1 - alpha);

@@ -161,3 +161,47 @@ def test_frames_in_flight_match_serial(pkg, oracle, gpu):
     dev.close()
     ref = oracle.stages(oracle.activate_records(rec), poses[3].view(oracle.UNIFORMS_DT))["image"]
     assert np.abs(serial[3] - ref).max() <= PIXEL_TOL
+
+
+def test_non_finite_inputs_do_not_break_parity(pkg, oracle, gpu):
+    """NaN / Inf / huge values in the scene: nothing hangs, and every stage still equals the oracle bit for bit
+    (such Gaussians end up culled or contribute garbage identically on both sides)."""
+    rec = pkg.synth.synth_records(4000, seed=14, kind="A")
+    rec[10, 0] = np.nan            # position
+    rec[11, 2] = np.inf
+    rec[12, 55:58] = 40.0          # exp(40): enormous splat
+    rec[13, 55:58] = -60.0         # exp(-60): degenerate covariance
+    rec[14, 58:62] = 0.0           # zero quaternion -> normalisation divides by zero
+    rec[15, 54] = np.nan           # opacity
+    rec[16, 6:9] = 1e30            # colour
+    rec[17, 2] = -0.2000001        # just beyond the 0.2 depth cull
+    verts = oracle.activate_records(rec)
+    u = oracle.camera_uniforms(oracle.default_camera(), 320, 192)
+    ref = oracle.stages(verts, u)
+    scene = pkg.Scene.from_records(rec, device=0)
+    rend = pkg.Renderer(scene)
+    img, _ = rend.render_host(pkg.camera_uniforms(pkg.make_camera(), 320, 192))
+    np.testing.assert_array_equal(rend.stage("tiles"), ref["tiles"])
+    np.testing.assert_array_equal(rend.stage("sorted_gid"), ref["sorted_payload"])
+    np.testing.assert_array_equal(rend.stage("ranges", u), ref["boundaries"])
+    both_nan = np.isnan(img) & np.isnan(ref["image"])
+    np.testing.assert_array_equal(np.where(both_nan, 0, img).view(np.uint32), np.where(both_nan, 0, ref["image"]).view(np.uint32))
+
+
+def test_renderer_reuse_across_resolutions(pkg, oracle, gpu):
+    """One renderer, changing framebuffer sizes and frames in flight: buffers are re-sized behind queued frames."""
+    rec = pkg.synth.synth_records(8000, seed=15, kind="A")
+    verts = oracle.activate_records(rec)
+    scene = pkg.Scene.from_records(rec, device=0)
+    rend = pkg.Renderer(scene)
+    rend.set_frames_in_flight(3)
+    dev = _HipBuffers()
+    sizes = [(320, 200), (1920, 1080), (64, 64), (4096, 2304), (320, 200), (800, 608)]
+    targets = [(dev.alloc(w * h * 16), w, h) for w, h in sizes]
+    for ptr, w, h in targets:
+        rend.render(pkg.camera_uniforms(pkg.make_camera(), w, h), ptr, 0)
+    rend.synchronize()
+    for ptr, w, h in targets:
+        ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), w, h))["image"]
+        np.testing.assert_array_equal(dev.download(ptr, (h, w, 4), np.float32), ref)
+    dev.close()
