@@ -140,9 +140,11 @@ def main():
     # diagnostic only: the same frame with ONE frame in flight, so that per-pass spans are not stretched by
     # the other streams' kernels (the timed region above overlaps frames; its spans include that contention)
     rend.set_frames_in_flight(1)
-    for i in range(30):
+    ts = time.perf_counter()
+    for i in range(100):
         submit(i)
     rend.synchronize()
+    serial_fps = 100 / (time.perf_counter() - ts)
     ssum, sframes = rend.timing_totals(reset=True)
     if rank == 0:
         fps = world * args.steps / elapsed
@@ -176,6 +178,7 @@ def main():
                        "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries), "tiles": T, "output": "rgba32f" + ("+bgra8" if args.bgra8 else ""),
                        "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}"},
             "gpu_ms_per_frame": round(sums.ms_total / max(frames, 1), 4),
+            "frames_per_s_one_in_flight": round(serial_fps, 2),  # diagnostic: one frame at a time (latency-bound)
             "passes": per_pass,
             "passes_serial_ms": {k: round(getattr(ssum, "ms_" + k) / max(sframes, 1), 4) for k in names + ["total"]},
             "roofline": {"kernel": {"render": "k_blend"}.get(dom, dom), "bound": "hbm",

@@ -11,8 +11,9 @@
  * All functions return 0 on success and a negative gs_status on failure;
  * gs_last_error() returns the message for the calling thread (the reference
  * throws std::runtime_error with the same text, e.g. GSScene.h:29).
- * Handles are not thread-safe; one HIP stream per renderer; one frame in
- * flight per renderer (VulkanContext.h:6 FRAMES_IN_FLIGHT 1).
+ * Handles are not thread-safe.  By default a renderer has one HIP stream and one
+ * frame in flight (VulkanContext.h:6 FRAMES_IN_FLIGHT 1); gs_set_frames_in_flight(k)
+ * gives it k buffer sets on k streams.
  */
 #ifndef GS3D_HIP_H
 #define GS3D_HIP_H
