@@ -542,7 +542,7 @@ struct gs_renderer {
         }
 
         // ---- blend ----
-        gs::launch_blend(ranges.p, sorted_gid, av, u.width, u.height, d_rgba, d_bgra, stream);
+        gs::launch_blend(ranges.p, sorted_gid, av, u.width, u.height, d_rgba, d_bgra, num_sets > 1 ? 16384u : 0u, stream);
         HIP_CHECK(hipEventRecord(ev[7], stream));
         HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipEventRecord(sl.done, stream));
