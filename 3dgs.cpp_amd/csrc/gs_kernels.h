@@ -72,7 +72,7 @@ struct RadixPass {
 };
 void launch_radix_pass(const RadixPass& p, hipStream_t s);
 
-// Exclusive scan of cnt[0..*n) -> off, total -> *total_out (3 kernels, fixed grid).
+// Exclusive scan of cnt[0..*n) -> off, total -> *total_out (2 kernels, fixed grid).
 void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n, uint32_t n_bound,
                            uint32_t* partial, uint32_t* total_out, hipStream_t s);
 

@@ -585,7 +585,7 @@ void launch_radix_pass(const RadixPass& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Exclusive scan (reduce / spine / downsweep), fixed grid of kScanBlocks.
+// Exclusive scan (reduce, then downsweep with the spine folded in), fixed grid of kScanBlocks.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
     // contiguous, 1024-aligned slices
@@ -610,23 +610,24 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(const uint32_t* __restric
     if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(kScanBlocks) void k_scan_spine(uint32_t* partial, uint32_t* total_out) {
-    __shared__ uint32_t scratch[8];
-    uint32_t v = partial[threadIdx.x], total;
-    uint32_t excl = block_excl_scan<kScanBlocks>(v, scratch, &total);
-    partial[threadIdx.x] = excl;
-    if (threadIdx.x == 0) *total_out = total;
-}
-
 __global__ __launch_bounds__(BLOCK) void k_scan_down(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
                                                      const uint32_t* n_ptr, uint32_t n_bound,
-                                                     const uint32_t* partial) {
+                                                     const uint32_t* partial, uint32_t* total_out) {
     __shared__ uint32_t scratch[8];
     uint32_t n = *n_ptr;
     if (n > n_bound) n = n_bound;
     uint32_t lo, hi;
     scan_range(n, lo, hi);
-    uint32_t running = partial[blockIdx.x];
+    static_assert(kScanBlocks == 2 * BLOCK, "the folded spine reads two partials per thread");
+    // spine folded in: every block sums the kScanBlocks (= 2 x 256) block partials before its own (2 KB, L2)
+    uint32_t running, grand;
+    {
+        const uint32_t p0 = partial[threadIdx.x], p1 = partial[threadIdx.x + BLOCK];
+        const uint32_t mine = (threadIdx.x < blockIdx.x ? p0 : 0u) + (threadIdx.x + BLOCK < blockIdx.x ? p1 : 0u);
+        block_excl_scan<BLOCK>(mine, scratch, &running);
+        block_excl_scan<BLOCK>(p0 + p1, scratch, &grand);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = grand;
+    }
     for (uint32_t base = lo; base < hi; base += 1024) {
         const uint32_t i0 = base + threadIdx.x * 4;  // base is 1024-aligned -> 16-byte aligned
         uint32_t v[4] = {0, 0, 0, 0};
@@ -656,8 +657,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_down(const uint32_t* __restrict_
 void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n, uint32_t n_bound,
                            uint32_t* partial, uint32_t* total_out, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_reduce, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, n, n_bound, partial);
-    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kScanBlocks), 0, s, partial, total_out);
-    hipLaunchKernelGGL(k_scan_down, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, off, n, n_bound, partial);
+    hipLaunchKernelGGL(k_scan_down, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, off, n, n_bound, partial, total_out);
 }
 
 // ---------------------------------------------------------------------------------------
