@@ -65,10 +65,9 @@ struct RadixPass {
     int bits;                 // significant bits in this digit (<= 8)
     int blocks;
     int first;
-    const uint32_t* gather_tiles;  // last depth pass: also emit tiles[value] in sorted order ...
-    const ushort4* gather_aabb;    // ... or, when set, the number of (tile >> bin_shift) bins its box touches ...
-    int bin_shift;
-    uint32_t* tiles_sorted;        // ... here (may be null)
+    const ushort4* gather_aabb;    // last depth pass: per sorted Gaussian, the number of (tile >> bin_shift) bins
+    int bin_shift;                 // its tile box touches ...
+    uint32_t* tiles_sorted;        // ... is written here (may be null)
 };
 void launch_radix_pass(const RadixPass& p, hipStream_t s);
 

@@ -368,7 +368,6 @@ struct RadixArgs {
     uint32_t* n_out;
     uint32_t* block_hist;
     uint32_t* digit_total;
-    const uint32_t* gather_tiles;
     const ushort4* gather_aabb;
     uint32_t* tiles_sorted;
     int bin_shift;
@@ -536,15 +535,11 @@ __global__ __launch_bounds__(BLOCK) void k_radix_scatter(RadixArgs a) {
                 const uint32_t dst = s_base[d] + (slot - s_texcl[d]);
                 a.keys_out[dst] = k2;
                 a.vals_out[dst] = v2;
-                if (a.tiles_sorted) {
-                    if (a.gather_aabb) {  // number of S x S-tile bins the Gaussian's tile box touches
-                        const ushort4 bx = a.gather_aabb[v2];
-                        const uint32_t nx = ((bx.z - 1u) >> a.bin_shift) - (bx.x >> a.bin_shift) + 1u;
-                        const uint32_t ny = ((bx.w - 1u) >> a.bin_shift) - (bx.y >> a.bin_shift) + 1u;
-                        a.tiles_sorted[dst] = nx * ny;
-                    } else {
-                        a.tiles_sorted[dst] = a.gather_tiles[v2];
-                    }
+                if (a.tiles_sorted) {  // number of S x S-tile bins the Gaussian's tile box touches
+                    const ushort4 bx = a.gather_aabb[v2];
+                    const uint32_t nx = ((bx.z - 1u) >> a.bin_shift) - (bx.x >> a.bin_shift) + 1u;
+                    const uint32_t ny = ((bx.w - 1u) >> a.bin_shift) - (bx.y >> a.bin_shift) + 1u;
+                    a.tiles_sorted[dst] = nx * ny;
                 }
             }
         }
@@ -566,7 +561,6 @@ void launch_radix_pass(const RadixPass& p, hipStream_t s) {
     a.n_out = p.n_out;
     a.block_hist = p.block_hist;
     a.digit_total = p.digit_total;
-    a.gather_tiles = p.gather_tiles;
     a.gather_aabb = p.gather_aabb;
     a.bin_shift = p.bin_shift;
     a.tiles_sorted = p.tiles_sorted;
