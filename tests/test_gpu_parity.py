@@ -205,3 +205,27 @@ def test_renderer_reuse_across_resolutions(pkg, oracle, gpu):
         ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), w, h))["image"]
         np.testing.assert_array_equal(dev.download(ptr, (h, w, 4), np.float32), ref)
     dev.close()
+
+
+def test_overflow_with_frames_in_flight(pkg, oracle, gpu):
+    """Four queued frames that all overflow the initial list capacity: every one is re-run after the buffers
+    grow (the redo path of the frame ring), and each lands in its own target."""
+    rec = pkg.synth.synth_records(300, seed=7, kind="A")
+    rec[:, 55:58] = 1.5  # every splat covers the screen: D = 300 x 8160 > the initial capacity of 2^20
+    w, h = 1920, 1080
+    verts = oracle.activate_records(rec)
+    scene = pkg.Scene.from_records(rec, device=0)
+    rend = pkg.Renderer(scene)
+    rend.set_frames_in_flight(4)
+    dev = _HipBuffers()
+    poses = [pkg.make_camera(position=(0.05 * k, 0.0, 0.0)) for k in range(4)]
+    targets = [dev.alloc(w * h * 16) for _ in poses]
+    for cam, ptr in zip(poses, targets):
+        rend.render(pkg.camera_uniforms(cam, w, h), ptr, 0)
+    rend.synchronize()
+    st = rend.stats()
+    assert st.retries >= 1 and st.num_instances > (1 << 20) and st.instance_capacity >= st.num_instances
+    for k, ptr in enumerate(targets):
+        ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(position=(0.05 * k, 0.0, 0.0)), w, h))["image"]
+        np.testing.assert_array_equal(dev.download(ptr, (h, w, 4), np.float32), ref)
+    dev.close()
