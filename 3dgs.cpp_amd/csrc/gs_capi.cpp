@@ -579,7 +579,7 @@ struct gs_renderer {
                 // D instances, or 4 x E1 level-1 candidates (the chunk table is sized from the capacity)
                 need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, 4ull * q.h_counters->bin_entries));
             }
-            need = need + need / 8 + 4096;
+            need = need + need / 2 + 4096;  // 1.5x head-room: a moving camera should not re-grow every few frames
             if (need > kMaxInstances) throw Error(GS_ERR_OVERFLOW, "more than 2^30 tile instances");
             if (retries > 64) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
             frames_enqueued -= pending;
