@@ -1154,9 +1154,9 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                                                  const float4* __restrict__ uv_rg, const float* __restrict__ bch,
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
                                                  float4* __restrict__ rgba, uchar4* __restrict__ bgra) {
-    // wave-private slabs (no cross-wave sharing, no barriers); one 48-byte record per entry so that a
-    // single scalar-derived address serves all three broadcast reads of the inner loop
-    __shared__ float4 s_rec[4][WAVE][4];  // {c00 c01 c11 o} {u v r g} {b, pmin, -, -} {pad}: 64-byte stride
+    // wave-private slabs (no cross-wave sharing, no barriers), three planes of 64 float4 per wave: {c00 c01 c11 o} {u v r g} {b, pmin, -, -}.  Plane-major keeps the staging
+    // ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets serve the reads
+    __shared__ float4 s_rec[4][3][WAVE];
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed only), and each
@@ -1215,18 +1215,18 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
             STAT_ADD(6, __popcll(__ballot(have)));
             STAT_ADD(1, __popcll(bm));
             if (bm == 0) continue;
-            s_rec[w][lane][0] = cur.co;
-            s_rec[w][lane][1] = cur.uv;
-            s_rec[w][lane][2] = make_float4(cur.b, -lim, 0.0f, 0.0f);
+            s_rec[w][0][lane] = cur.co;
+            s_rec[w][1][lane] = cur.uv;
+            s_rec[w][2][lane] = make_float4(cur.b, -lim, 0.0f, 0.0f);
 
             while (bm) {
                 const int k = __ffsll((unsigned long long)bm) - 1;
                 bm &= bm - 1;
                 STAT_ADD(2, 1);                       // (entry, wave) pairs evaluated
                 STAT_ADD(3, __popcll(alive));         // lanes alive
-                const float4 co = s_rec[w][k][0];
-                const float4 uv = s_rec[w][k][1];
-                const float4 bp = s_rec[w][k][2];
+                const float4 co = s_rec[w][0][k];
+                const float4 uv = s_rec[w][1][k];
+                const float4 bp = s_rec[w][2][k];
                 const float dx = uv.x - fx;
                 const float dy = uv.y - fy;
                 // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
