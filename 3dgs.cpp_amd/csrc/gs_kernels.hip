@@ -1224,9 +1224,12 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                 bm &= bm - 1;
                 STAT_ADD(2, 1);                       // (entry, wave) pairs evaluated
                 STAT_ADD(3, __popcll(alive));         // lanes alive
-                const float4 co = s_rec[w][0][k];
-                const float4 uv = s_rec[w][1][k];
-                const float4 bp = s_rec[w][2][k];
+                float4 co = s_rec[w][0][k];
+                float4 uv = s_rec[w][1][k];
+                float4 bp = s_rec[w][2][k];
+                // all ten floats in one LDS round trip: without this the compiler sinks the loads of o, r, g, b
+                // behind the exp() branch, where 94 % of the pairs then pay a second LDS latency
+                asm volatile("" : "+v"(co.w), "+v"(uv.z), "+v"(uv.w), "+v"(bp.x));
                 const float dx = uv.x - fx;
                 const float dy = uv.y - fy;
                 // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
