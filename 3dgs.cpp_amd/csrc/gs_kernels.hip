@@ -815,35 +815,61 @@ __device__ __forceinline__ void bin_cover_masks(int shift, int lx0, int ly0, int
     }
 }
 
-// Per-wave walk over its 64 candidates with lanes transposed onto tiles: candidate i's coverage word is
-// broadcast through a wave-private LDS slab (same-address read) and every lane tests its own bit in the VALU
-// (no exec-mask juggling, no SGPR round trips: the walk is otherwise bound by the CU's scalar unit and by
-// v_readlane hazards); "append candidate i to the lists of the tiles it covers, in order"
-// is then `store id at cursor; cursor += hit`.  The store is a raw buffer store whose offset is forced out of
-// range on lanes that miss, so the hardware's bounds check drops it (and enforces the list capacity) without a
-// branch.  FILL = false only counts.
+// 64 x 64 bit-matrix transpose across a wave: lane k enters with row k, lane t leaves with column t
+// (bit k of the result = bit t of lane k's input).  Six butterfly steps; step j swaps the off-diagonal j x j
+// blocks between lanes l and l ^ j.  ds_swizzle is a lane permutation inside 32-lane halves (no LDS memory).
+template <int J>
+__device__ __forceinline__ uint32_t transpose_step(uint32_t x, bool up) {
+    constexpr uint32_t MASK = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu
+                            : J == 2 ? 0x33333333u : 0x55555555u;
+    const uint32_t p = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (J << 10) | 0x1F);  // lane ^ J
+    return up ? (((p >> J) & MASK) | (x & ~MASK)) : ((x & MASK) | ((p & MASK) << J));
+}
+__device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, uint32_t lane) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    {   // j = 32: the low lanes' high words and the high lanes' low words change places
+        const bool up = (lane & 32u) != 0;
+        const uint32_t recv = (uint32_t)__shfl_xor((int)(up ? lo : hi), 32);
+        if (up) lo = recv; else hi = recv;
+    }
+    { const bool up = (lane & 16u) != 0; lo = transpose_step<16>(lo, up); hi = transpose_step<16>(hi, up); }
+    { const bool up = (lane & 8u) != 0;  lo = transpose_step<8>(lo, up);  hi = transpose_step<8>(hi, up); }
+    { const bool up = (lane & 4u) != 0;  lo = transpose_step<4>(lo, up);  hi = transpose_step<4>(hi, up); }
+    { const bool up = (lane & 2u) != 0;  lo = transpose_step<2>(lo, up);  hi = transpose_step<2>(hi, up); }
+    { const bool up = (lane & 1u) != 0;  lo = transpose_step<1>(lo, up);  hi = transpose_step<1>(hi, up); }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Per-wave expansion of its 64 candidates into the tiles of the bin.  Lane k enters with candidate k's coverage
+// words; a bit-matrix transpose per word puts lane t in possession of tile t's column: which of the 64
+// candidates cover it, in candidate (= depth) order.  Counting is a popcount.  Filling walks each lane's own
+// set bits: "k = lowest set bit, store ids[k] at cursor, cursor++", for as many rounds as the fullest tile of
+// the chunk needs (typically 8-16, where a candidate-major walk issues 64 mostly-empty scattered stores: the
+// scattered-store issue rate is what bounds this kernel).  The store is a raw buffer store whose offset is
+// forced out of range on lanes that have run dry, so the hardware's bounds check drops it (and enforces the
+// list capacity) without a branch.
 template <int R, bool FILL>
-__device__ __forceinline__ void bin_walk(const uint64_t (&m)[R], uint32_t g, uint32_t (&cursor)[R], uint32_t nvalid,
-                                         __amdgpu_buffer_rsrc_t out, uint64_t* __restrict__ slab /* wave-private [64][R] */) {
+__device__ __forceinline__ void bin_walk(const uint64_t (&m)[R], uint32_t (&cursor)[R], __amdgpu_buffer_rsrc_t out,
+                                         const uint32_t* __restrict__ ids /* wave-private [64]: the candidates' ids */) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t bit_lo = lane < 32 ? (1u << lane) : 0u, bit_hi = lane >= 32 ? (1u << (lane - 32)) : 0u;
-    uint32_t present = 0;  // which of the R words are non-zero for this lane's candidate
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        present |= (m[r] != 0 ? 1u : 0u) << r;
-        slab[lane * R + r] = m[r];  // broadcast source: same-address LDS reads, results stay in VGPRs
-    }
-    const uint32_t n = __builtin_amdgcn_readfirstlane(nvalid);
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t gi = FILL ? __builtin_amdgcn_readlane(g, i) : 0u;
-        const uint32_t pres = R > 1 ? __builtin_amdgcn_readlane(present, i) : 1u;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (R > 1 && !((pres >> r) & 1u)) continue;  // uniform: most candidates touch one or two words
-            const uint64_t cm = slab[i * R + r];
-            const bool hit = (((uint32_t)cm & bit_lo) | ((uint32_t)(cm >> 32) & bit_hi)) != 0;
-            if (FILL) __builtin_amdgcn_raw_buffer_store_b32(gi, out, hit ? cursor[r] * 4u : 0xFFFFFFFFu, 0, 0);
-            cursor[r] += hit ? 1u : 0u;
+        if (R > 1 && __builtin_amdgcn_ballot_w64(m[r] != 0) == 0) {  // uniform: no candidate touches this word
+            if (!FILL) cursor[r] = 0;
+            continue;
+        }
+        uint64_t col = wave_transpose64(m[r], lane);
+        if (!FILL) {
+            cursor[r] = (uint32_t)__popcll(col);
+            continue;
+        }
+        uint32_t cur = cursor[r];
+        while (__builtin_amdgcn_ballot_w64(col != 0) != 0) {
+            const bool on = col != 0;
+            const uint32_t k = (uint32_t)(__ffsll((unsigned long long)col) - 1) & 63u;
+            __builtin_amdgcn_raw_buffer_store_b32(ids[k], out, on ? cur * 4u : 0xFFFFFFFFu, 0, 0);
+            cur += on ? 1u : 0u;
+            col &= col - 1;
         }
     }
 }
@@ -851,7 +877,6 @@ __device__ __forceinline__ void bin_walk(const uint64_t (&m)[R], uint32_t g, uin
 template <int R>
 __global__ __launch_bounds__(BLOCK) void k_bin_count(BinArgs a) {
     __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
-    __shared__ uint64_t s_slab[4][64 * R];
     uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     constexpr int SS = 64 * R;
@@ -876,9 +901,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin_count(BinArgs a) {
         }
         bin_cover_masks<R>(a.shift, lx0, ly0, lx1, ly1, m);
         uint32_t cursor[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) cursor[r] = 0;
-        bin_walk<R, false>(m, g, cursor, count, __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, 0, 0x27000), s_slab[w]);
+        bin_walk<R, false>(m, cursor, __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, 0, 0x27000), nullptr);
         uint32_t* out = a.chunk_hist + (size_t)chunk * SS;
 #pragma unroll
         for (int r = 0; r < R; ++r) out[r * 64 + lane] = cursor[r];
@@ -993,7 +1016,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(BinArgs a) {
 template <int R>
 __global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
     __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
-    __shared__ uint64_t s_slab[4][64 * R];
+    __shared__ uint32_t s_ids[4][WAVE];
     const uint32_t total_chunks = min(bin_prepare(a, s_off, s_cpre, scratch), a.max_chunks);
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     constexpr int SS = 64 * R;
@@ -1026,7 +1049,8 @@ __global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
             const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
             cursor[r] = (x < a.tiles_x && y < a.tiles_y) ? a.ranges[2 * (y * a.tiles_x + x)] + prefix[t] : 0u;
         }
-        bin_walk<R, true>(m, g, cursor, count, out, s_slab[w]);  // append, in candidate order
+        s_ids[w][lane] = g;
+        bin_walk<R, true>(m, cursor, out, s_ids[w]);  // append, in candidate order
     }
 }
 
