@@ -400,7 +400,8 @@ struct gs_renderer {
     void init() {
         HIP_CHECK(hipSetDevice(scene->device));
         for (auto& sl : slots) {
-            for (auto& e : sl.ev) HIP_CHECK(hipEventCreate(&e));
+            // span timestamps only: no system-scope fence (L2 write-back) between the passes; `done` keeps the fence
+            for (auto& e : sl.ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
             HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(gs::Counters), hipHostMallocDefault));
             *sl.h_counters = gs::Counters{};
