@@ -455,9 +455,12 @@ struct gs_renderer {
         gs::AttrView av{tiles.p, depth.p, radius.p, aabb.p, conic_op.p, uv_rg.p, bch.p};
         gs::Counters* cnt = counters.p;
 
-        HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(gs::Counters), stream));
+        // the first and the last kernel of the frame clear / publish the counters themselves; the blit nodes (and
+        // their fences) are only needed when one of the two is not launched
+        const bool fused_counters = n != 0 && u.width != 0 && u.height != 0;
+        if (!fused_counters) HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(gs::Counters), stream));
         HIP_CHECK(hipEventRecord(ev[0], stream));
-        gs::launch_preprocess(sv, u, av, stream);
+        gs::launch_preprocess(sv, u, av, cnt, stream);
         if (timing) HIP_CHECK(hipEventRecord(ev[1], stream));
 
         // ---- depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
@@ -543,9 +546,10 @@ struct gs_renderer {
         }
 
         // ---- blend ----
-        gs::launch_blend(ranges.p, sorted_gid, av, u.width, u.height, d_rgba, d_bgra, num_sets > 1 ? 16384u : 0u, stream);
+        gs::launch_blend(ranges.p, sorted_gid, av, u.width, u.height, d_rgba, d_bgra, num_sets > 1 ? 16384u : 0u, cnt,
+                         fused_counters ? sl.h_counters : nullptr, stream);
         HIP_CHECK(hipEventRecord(ev[7], stream));
-        HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));
+        if (!fused_counters) HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipEventRecord(sl.done, stream));
         HIP_CHECK(hipGetLastError());
 

@@ -43,7 +43,9 @@ struct Counters {
 };
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s);
-void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, hipStream_t s);
+// counters (nullable): the kernel clears counters->overflow, so that a frame needs no memset node
+void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
+                       hipStream_t s);
 
 // Stable LSD radix pass on (u32 key, u32 value) pairs, 8-bit digit at `shift`.
 //   first != 0: the input is (key = bits(depth[i]), value = i) for every i < n_static with tiles[i] != 0
@@ -105,6 +107,7 @@ void launch_bin_fill(const BinLaunch& b, hipStream_t s);    // k_bin_fill
 // frames in flight, 16 KiB (4 instead of 8 workgroups per CU) leaves wave slots for the other frames'
 // latency-bound passes, which is worth ~4 % of throughput; 0 when frames run one at a time.
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const AttrView& av, uint32_t width,
-                  uint32_t height, float* rgba, uint8_t* bgra, uint32_t lds_pad, hipStream_t s);
+                  uint32_t height, float* rgba, uint8_t* bgra, uint32_t lds_pad, const Counters* counters,
+                  Counters* host_counters /* pinned, nullable: *host_counters = *counters */, hipStream_t s);
 
 }  // namespace gs

@@ -136,12 +136,14 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * 
 
 struct PreUniforms {
     gs_uniforms u;
+    Counters* counters;  // nullable
 };
 
 __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms pu, AttrView av) {
     const gs_uniforms& u = pu.u;
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= sv.n) return;
+    if (i == 0 && pu.counters) pu.counters->overflow = 0;  // first kernel of the frame: the only counter that is not plainly overwritten
     const size_t N = sv.n;
     const float* __restrict__ blob = sv.blob;
 
@@ -312,10 +314,12 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
     av.tiles[i] = num_tiles;  // :128 / :176
 }
 
-void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, hipStream_t s) {
+void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
+                       hipStream_t s) {
     if (sv.n == 0) return;
     PreUniforms pu;
     pu.u = u;
+    pu.counters = counters;
     hipLaunchKernelGGL(k_preprocess, dim3((sv.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, sv, pu, av);
 }
 
@@ -1177,12 +1181,16 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                                                  const float4* __restrict__ conic_op,
                                                  const float4* __restrict__ uv_rg, const float* __restrict__ bch,
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
-                                                 float4* __restrict__ rgba, uchar4* __restrict__ bgra) {
+                                                 float4* __restrict__ rgba, uchar4* __restrict__ bgra,
+                                                 const Counters* __restrict__ counters, Counters* host_counters) {
     // wave-private slabs (no cross-wave sharing, no barriers), three planes of 64 float4 per wave: {c00 c01 c11 o} {u v r g} {b, pmin, -, -}.  Plane-major keeps the staging
     // ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets serve the reads
     __shared__ float4 s_rec[4][3][WAVE];
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    // last kernel of the frame: hand V, D, E1 and the overflow flag to the host (pinned memory; visible to it once
+    // the frame's completion event, which carries the system-scope release, has fired) -- no copy node in the stream
+    if (host_counters && blockIdx.x == 0 && tid == 0) *host_counters = *counters;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed only), and each
     // XCD has a private 4 MiB L2.  Give every XCD one contiguous band of tiles so that the splat records its
     // tiles gather (neighbouring tiles share most of them) stay in that XCD's L2.  Bijective for any tile count.
@@ -1298,13 +1306,14 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
 }
 
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const AttrView& av, uint32_t width,
-                  uint32_t height, float* rgba, uint8_t* bgra, uint32_t lds_pad, hipStream_t s) {
+                  uint32_t height, float* rgba, uint8_t* bgra, uint32_t lds_pad, const Counters* counters,
+                  Counters* host_counters, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
     // lds_pad: unused dynamic LDS that only lowers the kernel's residency (see gs_kernels.h)
     hipLaunchKernelGGL(k_blend, dim3(tx * ty), dim3(BLOCK), lds_pad, s, reinterpret_cast<const uint2*>(ranges),
                        sorted_gid, av.conic_op, av.uv_rg, av.b, width, height, tx,
-                       reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra));
+                       reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters);
 }
 
 #ifdef GS_BLEND_STATS
