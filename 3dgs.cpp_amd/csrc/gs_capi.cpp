@@ -7,10 +7,15 @@
 // re-record (Renderer.cpp:391-399, 538) disappears.  D is copied back asynchronously at the end of
 // the frame only to detect instance-buffer overflow (Renderer.cpp:541-563 grows and retries too).
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <memory>
 #include <sstream>
@@ -181,7 +186,17 @@ size_t ply_type_size(const std::string& t) {
     return 0;
 }
 
-std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
+// What the header says about the payload: record count and stride, where the payload starts, and for each of the
+// 62 record slots the byte offset of its source property inside a file record (-1 = absent -> 0).
+struct PlyLayout {
+    uint64_t n = 0;
+    size_t stride = 0;
+    uint64_t data_offset = 0;
+    bool standard = false;  // exactly the reference's 62-float layout: records are used as they lie in the file
+    std::vector<long> src;
+};
+
+PlyLayout parse_ply_header(const std::string& path) {
     std::ifstream f(path, std::ios::binary);
     if (!f.is_open()) throw Error(GS_ERR_IO, "File does not exist: " + path);
     std::string line, format;
@@ -218,6 +233,9 @@ std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
     if (!format.empty() && format != "binary_little_endian")
         throw Error(GS_ERR_IO, "unsupported PLY format '" + format + "' (binary_little_endian only): " + path);
 
+    PlyLayout L;
+    L.n = static_cast<uint64_t>(n);
+    L.data_offset = static_cast<uint64_t>(f.tellg());
     static const char* const kStandard[] = {"x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"};
     bool standard = props.size() == gs::host::kRecordFloats || props.empty();
     for (size_t k = 0; standard && k < props.size(); ++k) {
@@ -229,17 +247,16 @@ std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
         else want = "rot_" + std::to_string(k - 58);
         standard = props[k].size == 4 && props[k].name == want && (props[k].type == "float" || props[k].type == "float32");
     }
-    std::vector<float> rec(static_cast<size_t>(n) * gs::host::kRecordFloats);
-    *n_out = static_cast<uint64_t>(n);
+    L.standard = standard;
     if (standard) {  // the reference's layout (or a header without property lines, which the reference also accepts)
-        f.read(reinterpret_cast<char*>(rec.data()), static_cast<std::streamsize>(rec.size() * sizeof(float)));
-        if (static_cast<size_t>(f.gcount()) != rec.size() * sizeof(float))
-            throw Error(GS_ERR_IO, "PLY payload is shorter than 'element vertex' x 62 floats: " + path);
-        return rec;
+        L.stride = gs::host::kRecordFloats * sizeof(float);
+        return L;
     }
 
     // name-mapped path: slot k of the 62-float record <- byte offset in the file's vertex record (or absent)
-    std::vector<long> src(gs::host::kRecordFloats, -1);
+    L.stride = stride;
+    std::vector<long>& src = L.src;
+    src.assign(gs::host::kRecordFloats, -1);
     auto find = [&](const std::string& name) -> long {
         for (const auto& p : props)
             if (p.name == name) {
@@ -266,23 +283,140 @@ std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
     const int per_channel = rest / 3;  // planar: all R, then all G, then all B
     for (int c = 0; c < 3; ++c)
         for (int j = 0; j < per_channel; ++j) src[9 + c * 15 + j] = find("f_rest_" + std::to_string(c * per_channel + j));
+    return L;
+}
 
-    std::vector<char> raw(static_cast<size_t>(n) * stride);
-    f.read(raw.data(), static_cast<std::streamsize>(raw.size()));
-    if (static_cast<size_t>(f.gcount()) != raw.size())
-        throw Error(GS_ERR_IO, "PLY payload is shorter than 'element vertex' x record size: " + path);
-    parallel_for(static_cast<uint64_t>(n), [&](uint64_t lo, uint64_t hi) {
-        for (uint64_t i = lo; i < hi; ++i) {
-            const char* in = raw.data() + i * stride;
-            float* out = rec.data() + i * gs::host::kRecordFloats;
-            for (int k = 0; k < gs::host::kRecordFloats; ++k) {
-                float v = 0.0f;  // absent: normals, higher-degree SH
-                if (src[k] >= 0) std::memcpy(&v, in + src[k], sizeof v);
-                out[k] = v;
-            }
+// one file record -> the 62-float PLY-domain record
+inline void ply_gather_record(const PlyLayout& L, const char* in, float* out) {
+    if (L.standard) {
+        std::memcpy(out, in, gs::host::kRecordFloats * sizeof(float));
+        return;
+    }
+    for (int k = 0; k < gs::host::kRecordFloats; ++k) {
+        float v = 0.0f;  // absent: normals, higher-degree SH
+        if (L.src[k] >= 0) std::memcpy(&v, in + L.src[k], sizeof v);
+        out[k] = v;
+    }
+}
+
+// The payload of a PLY, mapped read-only (files larger than RAM are paged through; offsets are 64-bit).
+struct MappedPly {
+    PlyLayout layout;
+    const char* base = nullptr;
+    size_t length = 0;
+    const char* payload = nullptr;
+    explicit MappedPly(const std::string& path) : layout(parse_ply_header(path)) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw Error(GS_ERR_IO, "File does not exist: " + path);
+        struct stat st {};
+        if (::fstat(fd, &st) != 0) {
+            ::close(fd);
+            throw Error(GS_ERR_IO, "cannot stat " + path);
         }
+        length = static_cast<size_t>(st.st_size);
+        const uint64_t need = layout.n * static_cast<uint64_t>(layout.stride);
+        if (length < layout.data_offset || length - layout.data_offset < need) {
+            ::close(fd);
+            throw Error(GS_ERR_IO, std::string("PLY payload is shorter than 'element vertex' x ") +
+                                       (layout.standard ? "62 floats: " : "record size: ") + path);
+        }
+        if (length) {
+            void* m = ::mmap(nullptr, length, PROT_READ, MAP_PRIVATE, fd, 0);
+            ::close(fd);
+            if (m == MAP_FAILED) throw Error(GS_ERR_IO, "cannot map " + path);
+            base = static_cast<const char*>(m);
+            (void)::madvise(m, length, MADV_SEQUENTIAL);
+        } else {
+            ::close(fd);
+        }
+        payload = base + layout.data_offset;
+    }
+    ~MappedPly() {
+        if (base) ::munmap(const_cast<char*>(base), length);
+    }
+    MappedPly(const MappedPly&) = delete;
+    MappedPly& operator=(const MappedPly&) = delete;
+};
+
+std::vector<float> read_ply(const std::string& path, uint64_t* n_out) {
+    MappedPly m(path);
+    const PlyLayout& L = m.layout;
+    std::vector<float> rec(static_cast<size_t>(L.n) * gs::host::kRecordFloats);
+    *n_out = L.n;
+    parallel_for(L.n, [&](uint64_t lo, uint64_t hi) {
+        if (L.standard) {  // the file records ARE the records
+            if (hi > lo) std::memcpy(rec.data() + lo * gs::host::kRecordFloats, m.payload + lo * L.stride, (hi - lo) * L.stride);
+            return;
+        }
+        for (uint64_t i = lo; i < hi; ++i) ply_gather_record(L, m.payload + i * L.stride, rec.data() + i * gs::host::kRecordFloats);
     });
     return rec;
+}
+
+// GSScene::load without the host-side copies of the scene: the mapped payload is converted chunk by chunk on the
+// load-time worker threads (gather by name -> activation -> the blob's planes) into two pinned staging buffers and
+// streamed to HBM while the next chunk is being converted.  Host memory stays at ~120 MB whatever the file size.
+void load_ply_streamed(gs_scene* s, const std::string& path) {
+    MappedPly m(path);
+    const PlyLayout& L = m.layout;
+    const uint64_t n = L.n;
+    if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
+    s->n = n;
+    s->owned_blob.alloc(static_cast<size_t>(gs::P_COUNT) * n);
+    s->blob = s->owned_blob.p;
+    if (n) {
+        constexpr uint64_t kChunk = 1ull << 18;
+        const uint64_t chunk = std::min(kChunk, n);
+        float* stage[2] = {nullptr, nullptr};
+        hipEvent_t freed[2] = {nullptr, nullptr};
+        hipStream_t up = nullptr;
+        auto cleanup = [&] {
+            for (int k = 0; k < 2; ++k) {
+                if (stage[k]) (void)hipHostFree(stage[k]);
+                if (freed[k]) (void)hipEventDestroy(freed[k]);
+            }
+            if (up) (void)hipStreamDestroy(up);
+        };
+        try {
+            HIP_CHECK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) {
+                HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&stage[k]), static_cast<size_t>(gs::P_COUNT) * chunk * sizeof(float),
+                                        hipHostMallocDefault));
+                HIP_CHECK(hipEventCreateWithFlags(&freed[k], hipEventDisableTiming));
+            }
+            uint64_t c = 0;
+            for (uint64_t c0 = 0; c0 < n; c0 += chunk, ++c) {
+                const uint64_t cnt = std::min(chunk, n - c0);
+                float* buf = stage[c & 1];
+                if (c >= 2) HIP_CHECK(hipEventSynchronize(freed[c & 1]));  // the upload that last read this buffer
+                parallel_for(cnt, [&](uint64_t lo, uint64_t hi) {
+                    float rec[gs::host::kRecordFloats], v[gs::host::kVertexFloats];
+                    for (uint64_t j = lo; j < hi; ++j) {
+                        ply_gather_record(L, m.payload + (c0 + j) * L.stride, rec);
+                        gs::host::activate_record(rec, v);
+                        for (int k = 0; k < 3; ++k) buf[(gs::P_POS + k) * chunk + j] = v[k];
+                        for (int k = 0; k < 3; ++k) buf[(gs::P_SCALE + k) * chunk + j] = v[4 + k];
+                        for (int k = 0; k < 4; ++k) buf[(gs::P_ROT + k) * chunk + j] = v[8 + k];
+                        buf[static_cast<size_t>(gs::P_OPACITY) * chunk + j] = v[7];
+                        std::memcpy(buf + static_cast<size_t>(gs::P_SH) * chunk + j * 48, v + 12, 48 * sizeof(float));
+                    }
+                });
+                for (int p = 0; p < gs::P_SH; ++p)
+                    HIP_CHECK(hipMemcpyAsync(s->blob + static_cast<size_t>(p) * n + c0, buf + static_cast<size_t>(p) * chunk,
+                                             cnt * sizeof(float), hipMemcpyHostToDevice, up));
+                HIP_CHECK(hipMemcpyAsync(s->blob + static_cast<size_t>(gs::P_SH) * n + c0 * 48,
+                                         buf + static_cast<size_t>(gs::P_SH) * chunk, cnt * 48 * sizeof(float),
+                                         hipMemcpyHostToDevice, up));
+                HIP_CHECK(hipEventRecord(freed[c & 1], up));
+            }
+            HIP_CHECK(hipStreamSynchronize(up));
+        } catch (...) {
+            cleanup();
+            throw;
+        }
+        cleanup();
+    }
+    s->finish_load();
 }
 
 }  // namespace
@@ -674,12 +808,11 @@ int gs_read_ply(const char* path, float* records, uint64_t capacity, uint64_t* n
 int gs_scene_load_ply(const char* path, int device, gs_scene** out) {
     return guarded([&] {
         if (!path || !out) throw Error(GS_ERR_INVALID, "null argument");
-        uint64_t n = 0;
-        std::vector<float> rec = read_ply(path, &n);  // IO errors first, like GSScene's ctor
+        (void)parse_ply_header(path);  // IO / format errors first, like GSScene's ctor, before any device is touched
         select_device(device);
         auto s = std::make_unique<gs_scene>();
         s->device = device;
-        activate_and_upload(s.get(), rec.data(), n);
+        load_ply_streamed(s.get(), path);
         *out = s.release();
     });
 }

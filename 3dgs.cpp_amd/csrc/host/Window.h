@@ -28,12 +28,18 @@ public:
 // Headless window for GPU servers: fixed size; tick() returns true GS_FRAMES times (default 1,
 // 0 = forever); pan deltas pushed through logTranslation accumulate like the reference's MetalWindow
 // (windowing/MetalWindow.cpp:24-45); GS_DUMP_DIR=<dir> writes each presented frame as frame_%05d.ppm.
+// GS_CAMERA_PATH=<file> scripts the polled input the GLFW window would report, one line per tick:
+//     <cursor dx> <cursor dy> <keys>
+// with keys a string over W A S D ' '->'_' shift->'^' escape->'x' ('-' = none); a line with a cursor delta also
+// reports mouse button 0 (the reference captures the mouse on that button, Renderer.cpp:36-44).  Lines are consumed
+// in order; after the last one the input is idle.  This makes a fly-through reproducible frame for frame.
 class HeadlessWindow final : public Window {
 public:
     HeadlessWindow(std::string name, int width, int height);
     [[nodiscard]] std::pair<uint32_t, uint32_t> getFramebufferSize() const override { return {width, height}; }
     std::array<double, 2> getCursorTranslation() override;
     std::array<bool, 3> getMouseButton() override { return {captureRequested, false, false}; }
+    std::array<bool, 7> getKeys() override { return keys; }
     bool tick() override;
     void logTranslation(float x, float y) override;
     bool wantsFrame() const override { return !dumpDir.empty(); }
@@ -49,4 +55,10 @@ private:
     double accumulatedX = 0, accumulatedY = 0;
     bool captureRequested = false;
     std::string dumpDir;
+    struct ScriptedInput {
+        double dx, dy;
+        std::array<bool, 7> keys;
+    };
+    std::vector<ScriptedInput> script;  // GS_CAMERA_PATH
+    std::array<bool, 7> keys{};
 };

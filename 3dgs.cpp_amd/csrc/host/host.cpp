@@ -27,9 +27,30 @@ HeadlessWindow::HeadlessWindow(std::string name_, int w, int h)
     : name(std::move(name_)), width(static_cast<uint32_t>(w)), height(static_cast<uint32_t>(h)) {
     frameBudget = std::atoll(env_or("GS_FRAMES", "1"));
     dumpDir = env_or("GS_DUMP_DIR", "");
+    const std::string path = env_or("GS_CAMERA_PATH", "");
+    if (!path.empty()) {
+        std::ifstream f(path);
+        if (!f) throw std::runtime_error("File does not exist: " + path);
+        double dx, dy;
+        std::string k;
+        while (f >> dx >> dy >> k) {
+            ScriptedInput in{dx, dy, {}};
+            const char* names = "WASD_^x";
+            for (char c : k)
+                for (int i = 0; i < 7; ++i)
+                    if (c == names[i]) in.keys[i] = true;
+            script.push_back(in);
+        }
+    }
 }
 bool HeadlessWindow::tick() {
     if (frameBudget > 0 && ticks >= frameBudget) return false;
+    keys = {};
+    if (static_cast<size_t>(ticks) < script.size()) {  // this tick's polled input
+        const ScriptedInput& in = script[static_cast<size_t>(ticks)];
+        keys = in.keys;
+        if (in.dx != 0.0 || in.dy != 0.0) logTranslation(static_cast<float>(in.dx), static_cast<float>(in.dy));
+    }
     ++ticks;
     return true;
 }

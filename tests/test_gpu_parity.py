@@ -3,6 +3,8 @@
 Tolerances: integer / index stages bit-exact; preprocess floats bit-exact (same operation order,
 no contraction); final fp32 RGB: max abs <= 1e-4 (BASELINE.json north_star), and in practice 0.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -229,3 +231,46 @@ def test_overflow_with_frames_in_flight(pkg, oracle, gpu):
         ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(position=(0.05 * k, 0.0, 0.0)), w, h))["image"]
         np.testing.assert_array_equal(dev.download(ptr, (h, w, 4), np.float32), ref)
     dev.close()
+
+
+def test_streamed_ply_ingest_matches_the_oracle_loader(pkg, oracle, gpu, tmp_path):
+    """gs_scene_load_ply maps the file and streams it to HBM in 2^18-Gaussian chunks (GSScene::load's role,
+    GSScene.cpp:26-68): the activated vertices in HBM must equal the oracle's loader bit for bit, across a chunk
+    boundary, for the reference's layout and for a name-mapped one."""
+    n = (1 << 18) + 12345
+    rec = pkg.synth.synth_records(n, seed=41, kind="A")
+    p_std = str(tmp_path / "std.ply")
+    pkg.synth.write_ply(p_std, rec)
+    want = oracle.load_ply(p_std).view(np.float32).reshape(-1, 60)
+    sc = pkg.Scene.load_ply(p_std)
+    assert sc.num_vertices == n
+    np.testing.assert_array_equal(sc.download_vertices().view(np.float32).reshape(-1, 60), want)
+    sc_rec = pkg.Scene.from_records(rec)
+    np.testing.assert_array_equal(sc.download_cov3d(), sc_rec.download_cov3d())
+    sc.close()
+    sc_rec.close()
+    # name-mapped: reversed property order, no normals, one extra double
+    names = [nm for nm in pkg.synth._PROPS if nm not in ("nx", "ny", "nz")][::-1]
+    dt = np.dtype([(nm, "<f4") for nm in names[:10]] + [("extra", "<f8")] + [(nm, "<f4") for nm in names[10:]])
+    data = np.zeros(n, dt)
+    for k, nm in enumerate(pkg.synth._PROPS):
+        if nm in dt.names:
+            data[nm] = rec[:, k]
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n
+    header += "".join("property %s %s\n" % ("double" if nm == "extra" else "float", nm) for nm in dt.names) + "end_header\n"
+    p_map = str(tmp_path / "mapped.ply")
+    with open(p_map, "wb") as f:
+        f.write(header.encode())
+        f.write(data.tobytes())
+    rec0 = rec.copy()
+    rec0[:, 3:6] = 0  # normals absent
+    want = oracle.activate_records(rec0).view(np.float32).reshape(-1, 60)
+    sc = pkg.Scene.load_ply(p_map)
+    np.testing.assert_array_equal(sc.download_vertices().view(np.float32).reshape(-1, 60), want)
+    sc.close()
+    # a truncated payload is an IO error, as in GSScene.cpp:36-41
+    with open(p_std, "r+b") as f:
+        f.truncate(os.path.getsize(p_std) - 100)
+    with pytest.raises(pkg.GsError) as e:
+        pkg.Scene.load_ply(p_std)
+    assert e.value.code == -2

@@ -84,3 +84,46 @@ def test_embedded_host_mode(pkg, oracle, gpu, tmp_path):
     ref = oracle_rgb8(oracle, verts, oracle.default_camera(position=(0.25, -0.5, 1.0), rotation=tuple(q)), w, h).astype(int)
     assert np.mean(np.abs(got - ref) > 1) < 0.02
     assert np.abs(got - read_ppm(tmp_path / "frame_00001.ppm").astype(int)).max() > 10  # the pan moved the view
+
+
+def test_scripted_camera_path_through_the_unchanged_viewer(pkg, oracle, gpu, tmp_path):
+    """GS_CAMERA_PATH feeds the headless window the input a GLFW window would poll; the frames must follow the
+    reference's input rules (Renderer.cpp:33-83): keys move 0.3 units per frame in the camera frame, a cursor
+    delta yaws then pitches by 0.005 rad per pixel."""
+    exe = os.path.join(PKG, "viewer_ref")
+    if not os.path.exists(exe):
+        pytest.skip("viewer_ref was not built (the reference tree was not mounted at build time)")
+    rec = pkg.synth.synth_records(5000, seed=14, kind="A")
+    ply = str(tmp_path / "scene.ply")
+    pkg.synth.write_ply(ply, rec)
+    path = tmp_path / "path.txt"
+    path.write_text("0 0 -\n0 0 S\n0 0 D_\n30 10 -\n0 0 W\n")
+    w, h = 256, 160
+    env = dict(os.environ, GS_FRAMES="6", GS_DUMP_DIR=str(tmp_path), GS_CAMERA_PATH=str(path))
+    out = subprocess.run([exe, "--no-gui", "--width", str(w), "--height", str(h), ply], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    verts = oracle.activate_records(rec)
+    # frames 0-2: identity rotation, so the moves are exact in float32: S = +z 0.3; D + space = normalize(1,1,0) * 0.3
+    d = np.float32(0.3) * (np.float32(1.0) / np.sqrt(np.float32(2.0)))
+    p1 = (0.0, 0.0, float(np.float32(0.3)))
+    p2 = (float(d), float(d), float(np.float32(0.3)))
+    for k, pos in enumerate([(0.0, 0.0, 0.0), p1]):
+        np.testing.assert_array_equal(read_ppm(tmp_path / f"frame_{k:05d}.ppm"),
+                                      oracle_rgb8(oracle, verts, oracle.default_camera(position=pos), w, h))
+    got2 = read_ppm(tmp_path / "frame_00002.ppm").astype(int)  # normalize() may differ from numpy's by an ulp
+    ref2 = oracle_rgb8(oracle, verts, oracle.default_camera(position=p2), w, h).astype(int)
+    assert np.mean(np.abs(got2 - ref2) > 1) < 0.002
+    # frame 3: yaw 30 px, pitch 10 px; frame 4: W = 0.3 along the rotated -z; frame 5: idle (script exhausted)
+    q = qmul(qmul(np.array([1.0, 0, 0, 0]), axis_angle(30 * 0.005, (0, -1, 0))), axis_angle(10 * 0.005, (-1, 0, 0)))
+    ref3 = oracle_rgb8(oracle, verts, oracle.default_camera(position=p2, rotation=tuple(q)), w, h).astype(int)
+    got3 = read_ppm(tmp_path / "frame_00003.ppm").astype(int)
+    assert np.mean(np.abs(got3 - ref3) > 1) < 0.02  # float32 sin/cos in C++ vs float64 here
+    qc = np.array([q[0], -q[1], -q[2], -q[3]])
+    fwd = qmul(qmul(q, np.array([0.0, 0, 0, -1.0])), qc)[1:]
+    p4 = tuple(np.array(p2) + 0.3 * fwd)
+    ref4 = oracle_rgb8(oracle, verts, oracle.default_camera(position=p4, rotation=tuple(q)), w, h).astype(int)
+    got4 = read_ppm(tmp_path / "frame_00004.ppm").astype(int)
+    assert np.mean(np.abs(got4 - ref4) > 1) < 0.02
+    assert np.abs(got4 - got3).max() > 10
+    np.testing.assert_array_equal(read_ppm(tmp_path / "frame_00005.ppm"), got4.astype(np.uint8))
