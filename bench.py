@@ -249,7 +249,7 @@ def cpu_baseline(n, w, h):
             break
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
             "sample": f"{frames} frame(s) of the same workload (N={n}, {w}x{h}, D={st.num_instances}) in {dt:.1f} s wall; "
-                      "oracle = CPU restatement of the reference shaders, OpenMP over Gaussians/tiles, sequential LSD sort",
+                      "oracle = CPU restatement of the reference shaders, OpenMP over Gaussians/tiles, sliced parallel LSD sort",
             "ms_per_pass": [round(x, 2) for x in (ms / frames)]}
 
 

@@ -556,25 +556,52 @@ void gso_sort_pairs(uint64_t* keys, uint32_t* payload, uint64_t d) {
     if (!k2 || !p2) abort();
     uint64_t *ks = keys, *kd = k2;
     uint32_t *ps = payload, *pd = p2;
+    /* stable LSD radix, 8 bits per pass.  Each thread owns one contiguous slice of the input: its histogram, then
+     * (digit-major, slice-minor) exclusive offsets, then an in-order scatter of its slice -- stable, and the result
+     * does not depend on the number of threads. */
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+    if (nt > 64) nt = 64;
+    if ((uint64_t)nt > d / 65536 + 1) nt = (int)(d / 65536 + 1);
+#endif
+    uint64_t* hist = (uint64_t*)malloc((size_t)nt * 256 * sizeof(uint64_t));
+    if (!hist) abort();
     for (int pass = 0; pass < 8; ++pass) {
         int shift = pass * 8;
-        uint64_t hist[256];
-        memset(hist, 0, sizeof hist);
-        for (uint64_t i = 0; i < d; ++i) hist[(ks[i] >> shift) & 255]++;
+        memset(hist, 0, (size_t)nt * 256 * sizeof(uint64_t));
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+#endif
+        for (int t = 0; t < nt; ++t) {
+            uint64_t lo = d * (uint64_t)t / (uint64_t)nt, hi = d * (uint64_t)(t + 1) / (uint64_t)nt;
+            uint64_t* h = hist + (size_t)t * 256;
+            for (uint64_t i = lo; i < hi; ++i) h[(ks[i] >> shift) & 255]++;
+        }
         int constant = 0;
-        for (int b = 0; b < 256; ++b)
-            if (hist[b] == d) constant = 1;
-        if (constant) continue;
         uint64_t sum = 0;
         for (int b = 0; b < 256; ++b) {
-            uint64_t c = hist[b];
-            hist[b] = sum;
-            sum += c;
+            uint64_t digit_total = 0;
+            for (int t = 0; t < nt; ++t) {
+                uint64_t c = hist[(size_t)t * 256 + b];
+                hist[(size_t)t * 256 + b] = sum;
+                sum += c;
+                digit_total += c;
+            }
+            if (digit_total == d) constant = 1;
         }
-        for (uint64_t i = 0; i < d; ++i) {
-            uint64_t pos = hist[(ks[i] >> shift) & 255]++;
-            kd[pos] = ks[i];
-            pd[pos] = ps[i];
+        if (constant) continue; /* every key has the same digit: the pass is the identity */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+#endif
+        for (int t = 0; t < nt; ++t) {
+            uint64_t lo = d * (uint64_t)t / (uint64_t)nt, hi = d * (uint64_t)(t + 1) / (uint64_t)nt;
+            uint64_t* h = hist + (size_t)t * 256;
+            for (uint64_t i = lo; i < hi; ++i) {
+                uint64_t pos = h[(ks[i] >> shift) & 255]++;
+                kd[pos] = ks[i];
+                pd[pos] = ps[i];
+            }
         }
         uint64_t* tk = ks;
         ks = kd;
@@ -587,6 +614,7 @@ void gso_sort_pairs(uint64_t* keys, uint32_t* payload, uint64_t d) {
         memcpy(keys, ks, d * sizeof(uint64_t));
         memcpy(payload, ps, d * sizeof(uint32_t));
     }
+    free(hist);
     free(k2);
     free(p2);
 }
