@@ -186,7 +186,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, n, w, h),
                          "note": "k_blend is FP32-VALU bound, not HBM bound (DESIGN.md §4): frac is its HBM view; "
                                  "valu = its share of the measured wave64 VALU issue rate",
-                         "valu": valu_view(dom, n, w, h, ms[dom])},
+                         "valu": valu_view(dom, n, w, h, ms[dom]),
+                         # the same kernel when it has the GPU to itself (frames one at a time): the timed region above
+                         # overlaps three frames, so its span there includes the other streams' kernels
+                         "one_in_flight": one_in_flight_view(dom, n, w, h, nbytes[dom], serial[dom])},
         }
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(n, w, h)
@@ -226,6 +229,13 @@ def valu_view(pass_name, n, w, h, ms):
                 "frac": round(insts / (ms * 1e-3) / peak, 4)}
     except (OSError, KeyError, ValueError):
         return None
+
+
+def one_in_flight_view(pass_name, n, w, h, nbytes, ms):
+    v = valu_view(pass_name, n, w, h, ms)
+    gbps = nbytes / 1e9 / (ms * 1e-3) if ms > 0 else 0.0
+    return {"ms": round(ms, 4), "achieved": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4),
+            "valu_frac": v["frac"] if v else None}
 
 
 def cpu_baseline(n, w, h):
