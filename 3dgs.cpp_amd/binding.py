@@ -32,7 +32,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_scene_num_vertices", "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
            "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_get_timing_totals",
-           "gs_get_stats", "gs_debug_download", "gs_renderer_stream"]
+           "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_renderer_stream"]
 
 
 class FrameStats(C.Structure):
@@ -226,6 +226,13 @@ class Renderer:
         n = C.c_uint64()
         _check(lib().gs_get_timing_totals(self._h, C.byref(st), C.byref(n), C.c_int(int(reset))))
         return st, n.value
+
+    def frame_intervals(self, reset=True, capacity=8192):
+        """ms between the completions of consecutive frames (GPU timestamps), oldest first."""
+        out = np.zeros(capacity, np.float32)
+        n = C.c_uint64()
+        _check(lib().gs_get_frame_intervals(self._h, _p(out), C.c_uint64(capacity), C.byref(n), C.c_int(int(reset))))
+        return out[:min(capacity, n.value)].copy()
 
     def stats(self):
         st = FrameStats()

@@ -490,6 +490,7 @@ struct FrameSlot {
 
 struct gs_renderer {
     static constexpr int kMaxInFlight = 8;
+    static constexpr int kSlots = kMaxInFlight + 1;  // one more than can be in flight: the previous frame's events stay readable
 
     gs_scene* scene = nullptr;
     bool timing = true;
@@ -501,7 +502,7 @@ struct gs_renderer {
 
     // frames in flight: a ring of descriptors, all enqueued on `stream` (so device buffers are
     // reused in stream order); the host only waits when the ring is full or on gs_synchronize.
-    FrameSlot slots[kMaxInFlight];
+    FrameSlot slots[kSlots];
     int in_flight_limit = 1;  // the reference has FRAMES_IN_FLIGHT 1 (VulkanContext.h:6)
     uint64_t frames_enqueued = 0;
     int pending = 0;
@@ -511,6 +512,10 @@ struct gs_renderer {
     uint32_t retries = 0;
     double total_ms[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t total_frames = 0;
+    // completion-to-completion intervals of consecutive frames (the frame time a consumer sees with frames in flight)
+    static constexpr size_t kIntervalRing = 8192;
+    std::vector<float> intervals;
+    bool prev_retired = false;  // the frame before the one being retired completed normally (its events are valid)
 
     uint32_t* sorted_gid = nullptr;  // result buffers of the last enqueued frame
     uint32_t* depth_order = nullptr;
@@ -553,7 +558,7 @@ struct gs_renderer {
 
     void enqueue(const gs_uniforms& u, float* d_rgba, uint8_t* d_bgra) {
         HIP_CHECK(hipSetDevice(scene->device));
-        FrameSlot& sl = slots[frames_enqueued % kMaxInFlight];
+        FrameSlot& sl = slots[frames_enqueued % kSlots];
         FrameBuffers& fb = sets[frames_enqueued % num_sets];
         hipStream_t stream = fb.stream;
         auto &tiles = fb.tiles, &tiles_sorted = fb.tiles_sorted, &offsets = fb.offsets, &block_hist = fb.block_hist,
@@ -695,7 +700,7 @@ struct gs_renderer {
         ++pending;
     }
 
-    FrameSlot& oldest() { return slots[(frames_enqueued - pending) % kMaxInFlight]; }
+    FrameSlot& oldest() { return slots[(frames_enqueued - pending) % kSlots]; }
 
     // Wait for the oldest queued frame; record its stats; on instance-buffer overflow grow the
     // buffers and re-run it and every frame queued behind it (Renderer.cpp:541-563 retries too).
@@ -713,7 +718,7 @@ struct gs_renderer {
             std::vector<Redo> redo;
             uint64_t need = 0;
             for (int k = 0; k < pending; ++k) {
-                FrameSlot& q = slots[(frames_enqueued - pending + k) % kMaxInFlight];
+                FrameSlot& q = slots[(frames_enqueued - pending + k) % kSlots];
                 redo.push_back({q.u, q.rgba, q.bgra});
                 // D instances, or 4 x E1 level-1 candidates (the chunk table is sized from the capacity)
                 need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, 4ull * q.h_counters->bin_entries));
@@ -723,6 +728,7 @@ struct gs_renderer {
             if (retries > 64) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
             frames_enqueued -= pending;
             pending = 0;
+            prev_retired = false;
             set_capacity(static_cast<uint32_t>(need));
             ++retries;
             for (const Redo& f : redo) enqueue(f.u, f.rgba, f.bgra);
@@ -755,6 +761,15 @@ struct gs_renderer {
                             st.ms_tile_boundary, st.ms_render, st.ms_total};
         for (int k = 0; k < 7; ++k) total_ms[k] += v[k];
         ++total_frames;
+        if (prev_retired) {
+            const uint64_t idx = frames_enqueued - pending;  // this frame; idx >= 1 here
+            float dt = 0.0f;
+            if (hipEventElapsedTime(&dt, slots[(idx - 1) % kSlots].ev[7], sl.ev[7]) == hipSuccess) {
+                if (intervals.size() >= kIntervalRing) intervals.erase(intervals.begin(), intervals.begin() + kIntervalRing / 2);
+                intervals.push_back(dt);
+            }
+        }
+        prev_retired = true;
         --pending;
     }
 
@@ -1002,6 +1017,20 @@ int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, 
         if (reset) {
             for (double& v : r->total_ms) v = 0.0;
             r->total_frames = 0;
+        }
+    });
+}
+
+int gs_get_frame_intervals(gs_renderer* r, float* out_ms, uint64_t capacity, uint64_t* n_out, int reset) {
+    return guarded([&] {
+        if (!r || !n_out || (!out_ms && capacity)) throw Error(GS_ERR_INVALID, "null argument");
+        r->drain();
+        const uint64_t n = std::min<uint64_t>(capacity, r->intervals.size());
+        if (n) std::memcpy(out_ms, r->intervals.data() + (r->intervals.size() - n), n * sizeof(float));
+        *n_out = r->intervals.size();
+        if (reset) {
+            r->intervals.clear();
+            r->prev_retired = false;
         }
     });
 }

@@ -121,6 +121,7 @@ def main():
         submit(i)
     sync_all()
     rend.timing_totals(reset=True)
+    rend.frame_intervals(reset=True)
 
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -135,6 +136,7 @@ def main():
         dist.barrier()
 
     sums, frames = rend.timing_totals(reset=True)
+    intervals = rend.frame_intervals(reset=True)  # completion-to-completion, GPU timestamps, this rank's K frames
     st = rend.stats()
 
     # diagnostic only: the same frame with ONE frame in flight, so that per-pass spans are not stretched by
@@ -177,6 +179,10 @@ def main():
                        "gaussians": int(st.num_gaussians), "visible": int(st.num_visible),
                        "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries), "tiles": T, "output": "rgba32f" + ("+bgra8" if args.bgra8 else ""),
                        "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}"},
+            # distribution of the per-frame time over the timed region (median + p5/p95), rank 0
+            "frame_ms": ({"p5": round(float(np.percentile(intervals, 5)), 4), "p50": round(float(np.percentile(intervals, 50)), 4),
+                          "p95": round(float(np.percentile(intervals, 95)), 4), "n": int(len(intervals))}
+                         if len(intervals) else None),
             "gpu_ms_per_frame": round(sums.ms_total / max(frames, 1), 4),
             "frames_per_s_one_in_flight": round(serial_fps, 2),  # diagnostic: one frame at a time (latency-bound)
             "passes": per_pass,

@@ -166,6 +166,11 @@ int gs_set_frames_in_flight(gs_renderer* r, int frames);
 /* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
  * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
 int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset);
+/* Completion-to-completion intervals (ms, GPU timestamps of the blend's end) of consecutive retired frames: the
+ * frame time a consumer sees with frames in flight -- what the reference's FPS counter samples once a second
+ * (Renderer.cpp:436-444), per frame.  Copies the most recent min(capacity, *n_out) values, oldest first; *n_out =
+ * number available (at most 8192 are kept).  Synchronizes. */
+int gs_get_frame_intervals(gs_renderer* r, float* out_ms, uint64_t capacity, uint64_t* n_out, int reset);
 /* Renderer::retrieveTimestamps (Renderer.cpp:85-100) for the last frame; synchronizes. */
 int gs_get_stats(gs_renderer* r, gs_frame_stats* out);
 /* Copy a stage buffer of the last frame to host memory; synchronizes. */

@@ -274,3 +274,32 @@ def test_streamed_ply_ingest_matches_the_oracle_loader(pkg, oracle, gpu, tmp_pat
     with pytest.raises(pkg.GsError) as e:
         pkg.Scene.load_ply(p_std)
     assert e.value.code == -2
+
+
+def test_frame_intervals_track_completions(pkg, gpu):
+    """gs_get_frame_intervals: one completion-to-completion interval per consecutive pair of retired frames, positive,
+    and consistent with the wall clock of the queued batch."""
+    import time
+    rec = pkg.synth.synth_records(20000, seed=3, kind="A")
+    scene = pkg.Scene.from_records(rec)
+    rend = pkg.Renderer(scene)
+    rend.set_frames_in_flight(3)
+    u = pkg.camera_uniforms(pkg.make_camera(), 320, 240)
+    hb = _HipBuffers()
+    ptrs = [hb.alloc(320 * 240 * 16) for _ in range(3)]
+    for i in range(6):
+        rend.render(u, ptrs[i % 3])
+    rend.synchronize()
+    rend.frame_intervals(reset=True)
+    t0 = time.perf_counter()
+    for i in range(50):
+        rend.render(u, ptrs[i % 3])
+    rend.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    iv = rend.frame_intervals(reset=True)
+    assert len(iv) == 49 and (iv > 0).all()
+    assert iv.sum() <= wall_ms * 1.05
+    assert len(rend.frame_intervals()) == 0
+    rend.close()
+    scene.close()
+    hb.close()
