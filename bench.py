@@ -73,6 +73,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()  # ranks that are shown a subset of the node's GPUs (HIP_VISIBLE_DEVICES)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
