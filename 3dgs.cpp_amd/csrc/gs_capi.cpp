@@ -516,6 +516,7 @@ struct gs_renderer {
     static constexpr size_t kIntervalRing = 8192;
     std::vector<float> intervals;
     bool prev_retired = false;  // the frame before the one being retired completed normally (its events are valid)
+    uint64_t latest_done = 0;   // index of the retired frame whose blend ended last (at most sets - 1 frames back)
 
     uint32_t* sorted_gid = nullptr;  // result buffers of the last enqueued frame
     uint32_t* depth_order = nullptr;
@@ -761,15 +762,20 @@ struct gs_renderer {
                             st.ms_tile_boundary, st.ms_render, st.ms_total};
         for (int k = 0; k < 7; ++k) total_ms[k] += v[k];
         ++total_frames;
-        if (prev_retired) {
-            const uint64_t idx = frames_enqueued - pending;  // this frame; idx >= 1 here
-            float dt = 0.0f;
-            if (hipEventElapsedTime(&dt, slots[(idx - 1) % kSlots].ev[7], sl.ev[7]) == hipSuccess) {
-                if (intervals.size() >= kIntervalRing) intervals.erase(intervals.begin(), intervals.begin() + kIntervalRing / 2);
-                intervals.push_back(dt);
+        {   // frames on different streams may finish out of order: measure against the latest completion so far
+            const uint64_t idx = frames_enqueued - pending;  // this frame
+            if (prev_retired) {
+                float dt = 0.0f;
+                if (hipEventElapsedTime(&dt, slots[latest_done % kSlots].ev[7], sl.ev[7]) == hipSuccess) {
+                    if (intervals.size() >= kIntervalRing) intervals.erase(intervals.begin(), intervals.begin() + kIntervalRing / 2);
+                    intervals.push_back(dt > 0.0f ? dt : 0.0f);  // 0: it had already finished when its predecessor did
+                    if (dt > 0.0f) latest_done = idx;
+                }
+            } else {
+                latest_done = idx;
             }
+            prev_retired = true;
         }
-        prev_retired = true;
         --pending;
     }
 

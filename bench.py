@@ -77,7 +77,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        backend = os.environ.get("GS_BENCH_BACKEND", "nccl")  # nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU
+        dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
 
     pkg = entry.load_package()
     n, w, h = args.gaussians, args.width, args.height
