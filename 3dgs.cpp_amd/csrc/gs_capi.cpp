@@ -557,6 +557,46 @@ struct gs_renderer {
         num_sets = k;
     }
 
+    // Blend workgroup -> tile table (shared by all buffer sets, rebuilt when the tile grid changes).  Workgroup b
+    // runs on XCD b % 8 (observed dispatch rule), each XCD has a private L2, and the dispatcher hands out workgroups
+    // in order, so a heavily loaded XCD holds the others back.  The screen is cut into blocks of B x B tiles and the
+    // blocks are dealt to the XCDs like a skewed checkerboard: every XCD gets blocks from all over the image (balanced
+    // for any scene) and the tiles of a block, which share most of their splat records, meet in one L2.
+    DevBuf<uint32_t> tile_order;
+    uint32_t order_tx = 0, order_ty = 0;
+    void ensure_tile_order(uint32_t tx, uint32_t ty) {
+        if (tx == order_tx && ty == order_ty && tile_order.p) return;
+        drain();
+        // B = 4 (64 x 64 px): on a clustered scene the blend takes 0.218 ms against 0.241 ms with one contiguous band
+        // of tiles per XCD (max/mean XCD load 1.01 against 1.54); B = 2, 6, 8 and the bands all measured equal or slower
+        constexpr uint32_t B = 4;
+        const uint64_t nt = static_cast<uint64_t>(tx) * ty;
+        std::vector<std::vector<uint32_t>> per_xcd(8);
+        const uint32_t nbx = (tx + B - 1) / B, nby = (ty + B - 1) / B;
+        for (uint32_t by = 0; by < nby; ++by)
+            for (uint32_t bx = 0; bx < nbx; ++bx) {
+                auto& list = per_xcd[(bx + 3 * by) % 8];
+                for (uint32_t y = by * B; y < std::min(ty, (by + 1) * B); ++y)
+                    for (uint32_t x = bx * B; x < std::min(tx, (bx + 1) * B); ++x) list.push_back(y * tx + x);
+            }
+        // workgroup b takes the next tile of XCD b % 8's list; lists that run dry borrow from the longest one
+        std::vector<uint32_t> order(nt);
+        size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint64_t b = 0; b < nt; ++b) {
+            int x = static_cast<int>(b % 8);
+            if (cursor[x] >= per_xcd[x].size()) {
+                size_t best = 0;
+                for (int k = 0; k < 8; ++k)
+                    if (per_xcd[k].size() - cursor[k] > best) best = per_xcd[k].size() - cursor[k], x = k;
+            }
+            order[b] = per_xcd[x][cursor[x]++];
+        }
+        tile_order.ensure(nt);
+        if (nt) HIP_CHECK(hipMemcpy(tile_order.p, order.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice));
+        order_tx = tx;
+        order_ty = ty;
+    }
+
     void enqueue(const gs_uniforms& u, float* d_rgba, uint8_t* d_bgra) {
         HIP_CHECK(hipSetDevice(scene->device));
         FrameSlot& sl = slots[frames_enqueued % kSlots];
@@ -590,6 +630,7 @@ struct gs_renderer {
             chunk_hist.ensure(static_cast<size_t>(max_chunks) * bin_tiles);
         }
         num_tiles = nt;
+        ensure_tile_order(tx, ty);
 
         gs::SceneView sv{scene->blob, scene->cov3d.p, n};
         gs::AttrView av{tiles.p, depth.p, radius.p, aabb.p, conic_op.p, uv_rg.p, bch.p};
@@ -686,7 +727,7 @@ struct gs_renderer {
         }
 
         // ---- blend ----
-        gs::launch_blend(ranges.p, sorted_gid, av, u.width, u.height, d_rgba, d_bgra, num_sets > 1 ? 16384u : 0u, cnt,
+        gs::launch_blend(ranges.p, sorted_gid, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, num_sets > 1 ? 16384u : 0u, cnt,
                          fused_counters ? sl.h_counters : nullptr, stream);
         HIP_CHECK(hipEventRecord(ev[7], stream));
         if (!fused_counters) HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));

@@ -1178,6 +1178,7 @@ __device__ __forceinline__ void blend_fetch(BlendEntry& e, uint32_t g, const flo
 
 __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ sorted_gid,
+                                                 const uint32_t* __restrict__ tile_order,
                                                  const float4* __restrict__ conic_op,
                                                  const float4* __restrict__ uv_rg, const float* __restrict__ bch,
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -1191,12 +1192,8 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     // last kernel of the frame: hand V, D, E1 and the overflow flag to the host (pinned memory; visible to it once
     // the frame's completion event, which carries the system-scope release, has fired) -- no copy node in the stream
     if (host_counters && blockIdx.x == 0 && tid == 0) *host_counters = *counters;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed only), and each
-    // XCD has a private 4 MiB L2.  Give every XCD one contiguous band of tiles so that the splat records its
-    // tiles gather (neighbouring tiles share most of them) stay in that XCD's L2.  Bijective for any tile count.
-    const uint32_t nb = gridDim.x, bq = nb / 8, br = nb % 8;
-    const uint32_t xcd = blockIdx.x % 8, bi = blockIdx.x / 8;
-    const uint32_t tile = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+    // XCD-aware, load-balanced tile order: a host-built table (gs_capi.cpp, ensure_tile_order)
+    const uint32_t tile = tile_order[blockIdx.x];
     const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const uint32_t qx0 = tile_x * kTile + (w & 1) * 8, qy0 = tile_y * kTile + (w >> 1) * 8;
     const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -1305,14 +1302,15 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     }
 }
 
-void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const AttrView& av, uint32_t width,
+void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
+                  uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, uint32_t lds_pad, const Counters* counters,
                   Counters* host_counters, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
     // lds_pad: unused dynamic LDS that only lowers the kernel's residency (see gs_kernels.h)
     hipLaunchKernelGGL(k_blend, dim3(tx * ty), dim3(BLOCK), lds_pad, s, reinterpret_cast<const uint2*>(ranges),
-                       sorted_gid, av.conic_op, av.uv_rg, av.b, width, height, tx,
+                       sorted_gid, tile_order, av.conic_op, av.uv_rg, av.b, width, height, tx,
                        reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters);
 }
 
