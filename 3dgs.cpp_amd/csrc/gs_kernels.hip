@@ -890,7 +890,13 @@ __global__ __launch_bounds__(BLOCK) void k_bin_count(BinArgs a) {
     }
     // the chunk loop is per wave: tell the compiler its control values are wave-uniform (scalar registers)
     const uint32_t wu = __builtin_amdgcn_readfirstlane((uint32_t)w);
-    for (uint32_t chunk = blockIdx.x * 4 + wu; chunk < total_chunks; chunk += gridDim.x * 4) {
+    // chunk -> wave: groups of 16 consecutive chunks (1024 candidates, nearly always one bin) stay on one XCD
+    // (workgroup b runs on XCD b % 8), so that the partial lines of that bin's tile lists are completed in one L2
+    const uint32_t xcd = blockIdx.x % 8, slot = (blockIdx.x / 8) * 4 + wu, slots = (gridDim.x / 8) * 4;
+    const uint32_t q_end = (((total_chunks + 15) / 16 + 7) / 8) * 16;
+    for (uint32_t q = slot; q < q_end; q += slots) {
+        const uint32_t chunk = ((q / 16) * 8 + xcd) * 16 + (q % 16);
+        if (chunk >= total_chunks) continue;
         uint32_t bin, first, count;
         bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
         bin = __builtin_amdgcn_readfirstlane(bin);
@@ -1029,7 +1035,13 @@ __global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
     const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, a.capacity * 4u, 0x27000);
     // the chunk loop is per wave: tell the compiler its control values are wave-uniform (scalar registers)
     const uint32_t wu = __builtin_amdgcn_readfirstlane((uint32_t)w);
-    for (uint32_t chunk = blockIdx.x * 4 + wu; chunk < total_chunks; chunk += gridDim.x * 4) {
+    // chunk -> wave: groups of 16 consecutive chunks (1024 candidates, nearly always one bin) stay on one XCD
+    // (workgroup b runs on XCD b % 8), so that the partial lines of that bin's tile lists are completed in one L2
+    const uint32_t xcd = blockIdx.x % 8, slot = (blockIdx.x / 8) * 4 + wu, slots = (gridDim.x / 8) * 4;
+    const uint32_t q_end = (((total_chunks + 15) / 16 + 7) / 8) * 16;
+    for (uint32_t q = slot; q < q_end; q += slots) {
+        const uint32_t chunk = ((q / 16) * 8 + xcd) * 16 + (q % 16);
+        if (chunk >= total_chunks) continue;
         uint32_t bin, first, count;
         bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
         bin = __builtin_amdgcn_readfirstlane(bin);
