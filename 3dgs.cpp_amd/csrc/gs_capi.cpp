@@ -471,7 +471,7 @@ struct FrameBuffers {
             ikeys[k].alloc(cap);
             ivals[k].alloc(cap);
         }
-        sorted.alloc(cap);
+        sorted.alloc(static_cast<size_t>(cap) + 4);  // + 4: a 16-byte list store that starts inside the capacity may end past it
     }
     ~FrameBuffers() {
         if (stream) (void)hipStreamDestroy(stream);

@@ -867,13 +867,31 @@ __device__ __forceinline__ void bin_walk(const uint64_t (&m)[R], uint32_t (&curs
             cursor[r] = (uint32_t)__popcll(col);
             continue;
         }
+        // up to four ids per lane and round, written with ONE store of 4..16 bytes: the lists are written at ~1 TB/s
+        // because every lane's store is its own request to the L2 (a different line per lane), so what counts is the
+        // number of requests, not of bytes.  One store instruction per size; lanes of another size are out of range.
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         uint32_t cur = cursor[r];
         while (__builtin_amdgcn_ballot_w64(col != 0) != 0) {
-            const bool on = col != 0;
-            const uint32_t k = (uint32_t)(__ffsll((unsigned long long)col) - 1) & 63u;
-            __builtin_amdgcn_raw_buffer_store_b32(ids[k], out, on ? cur * 4u : 0xFFFFFFFFu, 0, 0);
-            cur += on ? 1u : 0u;
-            col &= col - 1;
+            const uint32_t pc = (uint32_t)__popcll(col);
+            const uint32_t cnt = pc < 4u ? pc : 4u;
+            uint32_t id[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // an exhausted column reads slot 63 and drops the value below
+                id[j] = ids[(uint32_t)(__ffsll((unsigned long long)col) - 1) & 63u];
+                col &= col - 1;
+            }
+            const uint32_t off = cur * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32(id[0], out, cnt == 1u ? off : 0xFFFFFFFFu, 0, 0);
+            u32x2 v2 = {id[0], id[1]};
+            __builtin_amdgcn_raw_buffer_store_b64(v2, out, cnt == 2u ? off : 0xFFFFFFFFu, 0, 0);
+            u32x3 v3 = {id[0], id[1], id[2]};
+            __builtin_amdgcn_raw_buffer_store_b96(v3, out, cnt == 3u ? off : 0xFFFFFFFFu, 0, 0);
+            u32x4 v4 = {id[0], id[1], id[2], id[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(v4, out, cnt == 4u ? off : 0xFFFFFFFFu, 0, 0);
+            cur += cnt;
         }
     }
 }
