@@ -193,7 +193,9 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, n, w, h),
                          "note": "k_blend is FP32-VALU bound, not HBM bound (DESIGN.md §4): frac is its HBM view; "
-                                 "valu = its share of the measured wave64 VALU issue rate",
+                                 "valu = its share of the measured wave64 VALU issue rate.  The timed region keeps 3 frames "
+                                 "in flight, so a launch's span there includes the time it shares the CUs with the other "
+                                 "frames' launches; one_in_flight is the same kernel with the GPU to itself",
                          "valu": valu_view(dom, n, w, h, ms[dom]),
                          # the same kernel when it has the GPU to itself (frames one at a time): the timed region above
                          # overlaps three frames, so its span there includes the other streams' kernels
