@@ -31,7 +31,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_scene_from_vertices", "gs_scene_from_device_blob", "gs_scene_blob_floats", "gs_scene_blob",
            "gs_scene_num_vertices", "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
-           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_get_timing_totals",
+           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_get_timing_totals",
            "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_renderer_stream"]
 
 
@@ -40,7 +40,7 @@ class FrameStats(C.Structure):
                 ("instance_capacity", C.c_uint64), ("ms_preprocess", C.c_float), ("ms_prefix_sum", C.c_float),
                 ("ms_preprocess_sort", C.c_float), ("ms_sort", C.c_float), ("ms_tile_boundary", C.c_float),
                 ("ms_render", C.c_float), ("ms_total", C.c_float), ("retries", C.c_uint32),
-                ("num_bin_entries", C.c_uint32)]
+                ("num_bin_entries", C.c_uint32), ("max_bin_entries", C.c_uint32), ("sort_path", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -219,6 +219,10 @@ class Renderer:
 
     def set_frames_in_flight(self, frames):
         _check(lib().gs_set_frames_in_flight(self._h, C.c_int(int(frames))))
+
+    def set_sort_path(self, mode):
+        """0 automatic, 1 global depth order, 2 bin-local (gs_set_sort_path)."""
+        _check(lib().gs_set_sort_path(self._h, C.c_int(int(mode))))
 
     def timing_totals(self, reset=True):
         """(sums of per-pass ms as FrameStats, number of frames summed)."""

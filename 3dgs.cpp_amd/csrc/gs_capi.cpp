@@ -461,7 +461,7 @@ struct FrameBuffers {
         offsets.alloc(n);
         block_hist.alloc(256 * static_cast<size_t>(gs::kSortMaxBlocks));
         digit_total.alloc(256);
-        scan_partial.alloc(gs::kScanBlocks);
+        scan_partial.alloc(2 * gs::kScanBlocks);
         counters.alloc(1);
         set_capacity(capacity);
         ready = true;
@@ -486,6 +486,7 @@ struct FrameSlot {
     hipEvent_t done = nullptr;
     gs::Counters* h_counters = nullptr;  // pinned
     bool timed = false;
+    bool bin_local = false;  // the depth-order path this frame took
 };
 
 struct gs_renderer {
@@ -508,6 +509,14 @@ struct gs_renderer {
     int pending = 0;
 
     gs_frame_stats last{};  // stats of the most recently retired frame
+
+    // Which depth-order path a frame takes: bin-local = one in-LDS sort per bin after the binning
+    // (13 kernels per frame), global = the V visible Gaussians ordered first (26 kernels; any bin size).
+    // sort_mode 0 = automatic: bin-local unless the fullest bin of a recent frame does not fit k_bin_sort.
+    int sort_mode = 0;           // 0 auto, 1 global depth order, 2 bin-local (forced: a bin that does not fit is an error)
+    bool bin_local_ok = true;    // automatic mode: no recent frame had a bin beyond kBinSortMax
+    uint32_t frames_since_fallback = 0;
+    bool use_bin_local() const { return sort_mode == 2 || (sort_mode == 0 && bin_local_ok); }
     bool have_frame = false;
     uint32_t retries = 0;
     double total_ms[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -641,11 +650,14 @@ struct gs_renderer {
         const bool fused_counters = n != 0 && u.width != 0 && u.height != 0;
         if (!fused_counters) HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(gs::Counters), stream));
         HIP_CHECK(hipEventRecord(ev[0], stream));
-        gs::launch_preprocess(sv, u, av, cnt, stream);
+        const bool bin_local = use_bin_local();
+        // bin-local path: preprocess also emits the number of bins each Gaussian touches (index order)
+        gs::launch_preprocess(sv, u, av, cnt, bin_local ? tiles_sorted.p : nullptr, bin_shift, stream);
         if (timing) HIP_CHECK(hipEventRecord(ev[1], stream));
 
-        // ---- depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
-        {
+        const uint32_t* cand = nullptr;  // bin-major candidate ids, (depth, id) order inside a bin
+        if (!bin_local) {
+            // ---- depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
             const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (n + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
             const uint32_t* kin = reinterpret_cast<const uint32_t*>(depth.p);
             const uint32_t* vin = nullptr;
@@ -676,15 +688,21 @@ struct gs_renderer {
                 vin = dvals[dst].p;
             }
             depth_order = dvals[1].p;
+        } else {
+            depth_order = nullptr;
         }
         if (timing) HIP_CHECK(hipEventRecord(ev[2], stream));
 
         {
-            // ---- level 1: (bin, Gaussian) candidates in depth order, one stable pass by bin ----
-            gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, &cnt->visible, n, scan_partial.p, &cnt->bin_entries, stream);
+            // ---- level 1: (bin, Gaussian) candidates, one stable pass by bin ----
+            // global path: over the V visible Gaussians in depth order; bin-local path: over all N in index order
+            // (culled ones count 0 bins), and the scan also counts the visible ones
+            gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, bin_local ? nullptr : &cnt->visible, n, scan_partial.p,
+                                      &cnt->bin_entries, bin_local ? &cnt->visible : nullptr, stream);
             if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
-            gs::launch_duplicate(depth_order, offsets.p, tiles_sorted.p, aabb.p, &cnt->visible, n, bins_x, bin_shift,
-                                 capacity, ikeys[0].p, ivals[0].p, cnt, stream);
+            gs::launch_duplicate(bin_local ? nullptr : depth_order, offsets.p, tiles_sorted.p, aabb.p,
+                                 bin_local ? nullptr : &cnt->visible, n, bins_x, bin_shift, capacity, ikeys[0].p,
+                                 ivals[0].p, cnt, stream);
             if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
             {
                 gs::RadixPass p{};
@@ -701,10 +719,15 @@ struct gs_renderer {
                 p.blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (capacity + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
                 gs::launch_radix_pass(p, stream);
             }
+            cand = ivals[1].p;
+            if (bin_local) {  // inside each bin: index order -> (depth bits, id) order, in LDS
+                gs::launch_bin_sort(digit_total.p, ivals[1].p, depth.p, ivals[0].p, cnt, bins_x * bins_y, stream);
+                cand = ivals[0].p;
+            }
             if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
             // ---- level 2: per-tile counts -> ranges and D (tile_boundary), then the per-tile lists ----
             gs::BinLaunch b{};
-            b.cand = ivals[1].p;
+            b.cand = cand;
             b.bin_count = digit_total.p;
             b.aabb = aabb.p;
             b.chunk_hist = chunk_hist.p;
@@ -734,6 +757,7 @@ struct gs_renderer {
         HIP_CHECK(hipEventRecord(sl.done, stream));
         HIP_CHECK(hipGetLastError());
 
+        sl.bin_local = bin_local;
         sl.u = u;
         sl.rgba = d_rgba;
         sl.bgra = d_bgra;
@@ -759,28 +783,50 @@ struct gs_renderer {
             };
             std::vector<Redo> redo;
             uint64_t need = 0;
+            bool grow = false, bin_too_big = false;
             for (int k = 0; k < pending; ++k) {
                 FrameSlot& q = slots[(frames_enqueued - pending + k) % kSlots];
                 redo.push_back({q.u, q.rgba, q.bgra});
-                // D instances, or 4 x E1 level-1 candidates (the chunk table is sized from the capacity)
-                need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, 4ull * q.h_counters->bin_entries));
+                if (q.h_counters->overflow & 1u) {
+                    grow = true;
+                    // D instances, or 4 x E1 level-1 candidates (the chunk table is sized from the capacity)
+                    need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, 4ull * q.h_counters->bin_entries));
+                }
+                if (q.bin_local && (q.h_counters->overflow & 2u)) bin_too_big = true;
             }
-            need = need + need / 2 + 4096;  // 1.5x head-room: a moving camera should not re-grow every few frames
-            if (need > kMaxInstances) throw Error(GS_ERR_OVERFLOW, "more than 2^30 tile instances");
-            if (retries > 64) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
+            // the queued frames are dropped from the ring first: whatever is thrown below, the renderer stays usable
             frames_enqueued -= pending;
             pending = 0;
             prev_retired = false;
-            set_capacity(static_cast<uint32_t>(need));
+            if (bin_too_big) {  // a bin outgrew the in-LDS sort: take the global depth order from here on
+                if (sort_mode == 2) throw Error(GS_ERR_OVERFLOW, "a bin holds more candidates than the bin-local sort can order");
+                bin_local_ok = false;
+                frames_since_fallback = 0;
+            }
+            if (retries > 64) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
+            if (grow) {
+                need = need + need / 2 + 4096;  // 1.5x head-room: a moving camera should not re-grow every few frames
+                if (need > kMaxInstances) throw Error(GS_ERR_OVERFLOW, "more than 2^30 tile instances");
+                set_capacity(static_cast<uint32_t>(need));
+            }
             ++retries;
             for (const Redo& f : redo) enqueue(f.u, f.rgba, f.bgra);
             return;
+        }
+        if (sort_mode == 0 && !bin_local_ok) {  // back to the bin-local path once the bins have fitted for a while
+            if (sl.h_counters->max_bin <= static_cast<uint32_t>(gs::kBinSortMax) * 7 / 8) {
+                if (++frames_since_fallback >= 32) bin_local_ok = true;
+            } else {
+                frames_since_fallback = 0;
+            }
         }
         gs_frame_stats st{};
         st.num_gaussians = scene->n;
         st.num_visible = sl.h_counters->visible;
         st.num_instances = sl.h_counters->instances;
         st.num_bin_entries = sl.h_counters->bin_entries;
+        st.max_bin_entries = sl.h_counters->max_bin;
+        st.sort_path = sl.bin_local ? 2u : 1u;
         st.instance_capacity = capacity;
         auto span = [&](int a, int b) {
             float ms = 0.0f;
@@ -966,6 +1012,11 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
         auto r = std::make_unique<gs_renderer>();
         r->scene = scene;
         r->init();
+        if (const char* e = std::getenv("GS_SORT_PATH")) {  // initial gs_set_sort_path, for hosts that cannot call it (the viewer)
+            const int mode = std::atoi(e);
+            if (mode < 0 || mode > 2) throw Error(GS_ERR_INVALID, "GS_SORT_PATH must be 0 (auto), 1 (global) or 2 (bin-local)");
+            r->sort_mode = mode;
+        }
         *out = r.release();
     });
 }
@@ -1082,11 +1133,24 @@ int gs_get_frame_intervals(gs_renderer* r, float* out_ms, uint64_t capacity, uin
     });
 }
 
+int gs_set_sort_path(gs_renderer* r, int mode) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "renderer is null");
+        if (mode < 0 || mode > 2) throw Error(GS_ERR_INVALID, "sort path must be 0 (auto), 1 (global) or 2 (bin-local)");
+        r->drain();
+        r->sort_mode = mode;
+        r->bin_local_ok = true;
+        r->frames_since_fallback = 0;
+    });
+}
+
 int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
     return guarded([&] {
         if (!r || !dst) throw Error(GS_ERR_INVALID, "null argument");
         r->drain();
         if (!r->have_frame) throw Error(GS_ERR_INVALID, "no frame rendered yet");
+        if (stage == GS_STAGE_DEPTH_ORDER && !r->depth_order)
+            throw Error(GS_ERR_INVALID, "the depth-order tap exists only on the global depth-order path (gs_set_sort_path(r, 1))");
         const uint64_t n = r->scene->n, v = r->last.num_visible;
         const uint64_t d = std::min<uint64_t>(r->last.num_instances, r->capacity);
         const void* src = nullptr;

@@ -38,14 +38,21 @@ struct AttrView {
 struct Counters {
     uint32_t visible;    // V
     uint32_t instances;  // D (may exceed capacity: then `overflow` is set and nothing past capacity is written)
-    uint32_t overflow;
+    uint32_t overflow;   // bit 0: a capacity (lists, candidates, chunk table) was exceeded; bit 1: a bin outgrew k_bin_sort
     uint32_t bin_entries;  // E1: (bin, Gaussian) candidates of the level-1 binning
+    uint32_t max_bin;    // candidates in the fullest bin
+    uint32_t pad;
 };
+constexpr int kBinSortMax = 8192;  // candidates per bin that k_bin_sort can order in LDS (2 x 64 KiB of (key, id))
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s);
-// counters (nullable): the kernel clears counters->overflow, so that a frame needs no memset node
+// counters (nullable): the kernel clears counters->overflow, so that a frame needs no memset node.
+// nbins (nullable): [N] bins of (1 << bin_shift)^2 tiles touched by each Gaussian's tile box, 0 when culled.
 void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
-                       hipStream_t s);
+                       uint32_t* nbins, int bin_shift, hipStream_t s);
+// Bin-local depth order: bin-major candidate ids (index order inside a bin) -> (depth bits, id) order inside each bin.
+void launch_bin_sort(const uint32_t* bin_count, const uint32_t* ids_in, const float* depth, uint32_t* ids_out,
+                     Counters* counters, uint32_t bins, hipStream_t s);
 
 // Stable LSD radix pass on (u32 key, u32 value) pairs, 8-bit digit at `shift`.
 //   first != 0: the input is (key = bits(depth[i]), value = i) for every i < n_static with tiles[i] != 0
@@ -73,12 +80,14 @@ struct RadixPass {
 };
 void launch_radix_pass(const RadixPass& p, hipStream_t s);
 
-// Exclusive scan of cnt[0..*n) -> off, total -> *total_out (2 kernels, fixed grid).
+// Exclusive scan of cnt[0..*n) -> off, total -> *total_out (2 kernels, fixed grid).  n == nullptr: n_bound entries.
+// partial: 2 * kScanBlocks uints.  nonzero_out (nullable): number of non-zero entries.
 void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n, uint32_t n_bound,
-                           uint32_t* partial, uint32_t* total_out, hipStream_t s);
+                           uint32_t* partial, uint32_t* total_out, uint32_t* nonzero_out, hipStream_t s);
 
 // preprocess_sort.comp counterpart, in depth order: for j < *n_visible, g = order[j], writes
 // tile ids (x outer, y inner) and g at off[j]...  Sets counters->overflow when D > capacity.
+// order == nullptr: g = j; n_visible == nullptr: n_bound entries (entries with a zero count emit nothing).
 void launch_duplicate(const uint32_t* order, const uint32_t* off, const uint32_t* tiles_sorted,
                       const ushort4* aabb, const uint32_t* n_visible, uint32_t n_bound, uint32_t tiles_x,
                       int shift, uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,

@@ -137,13 +137,18 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * 
 struct PreUniforms {
     gs_uniforms u;
     Counters* counters;  // nullable
+    uint32_t* nbins;     // nullable: [N] number of S x S-tile bins the tile box touches (0 when culled), index order
+    int bin_shift;
 };
 
 __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms pu, AttrView av) {
     const gs_uniforms& u = pu.u;
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= sv.n) return;
-    if (i == 0 && pu.counters) pu.counters->overflow = 0;  // first kernel of the frame: the only counter that is not plainly overwritten
+    if (i == 0 && pu.counters) {  // first kernel of the frame: the counters that are not plainly overwritten
+        pu.counters->overflow = 0;
+        pu.counters->max_bin = 0;
+    }
     const size_t N = sv.n;
     const float* __restrict__ blob = sv.blob;
 
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
     const float py = blob[(P_POS + 1) * N + i];
     const float pz = blob[(P_POS + 2) * N + i];
 
-    uint32_t num_tiles = 0;
+    uint32_t num_tiles = 0, num_bins = 0;
     do {
         // preprocess.comp:130-135 (position.w == 1)
         float p_hom[4], p_view[3];
@@ -303,6 +308,8 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         if (rgb[0] < 0.0f) rgb[0] = 0.0f;
 
         num_tiles = nt;
+        num_bins = (uint32_t)(((bx1 - 1) >> pu.bin_shift) - (bx0 >> pu.bin_shift) + 1) *
+                   (uint32_t)(((by1 - 1) >> pu.bin_shift) - (by0 >> pu.bin_shift) + 1);
         av.depth[i] = p_view[2];
         av.radius[i] = radii;
         av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1,
@@ -312,14 +319,17 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         av.b[i] = rgb[2];
     } while (false);
     av.tiles[i] = num_tiles;  // :128 / :176
+    if (pu.nbins) pu.nbins[i] = num_bins;
 }
 
 void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
-                       hipStream_t s) {
+                       uint32_t* nbins, int bin_shift, hipStream_t s) {
     if (sv.n == 0) return;
     PreUniforms pu;
     pu.u = u;
     pu.counters = counters;
+    pu.nbins = nbins;
+    pu.bin_shift = bin_shift;
     hipLaunchKernelGGL(k_preprocess, dim3((sv.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, sv, pu, av);
 }
 
@@ -597,22 +607,31 @@ __device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& h
 __global__ __launch_bounds__(BLOCK) void k_scan_reduce(const uint32_t* __restrict__ cnt, const uint32_t* n_ptr,
                                                        uint32_t n_bound, uint32_t* partial) {
     __shared__ uint32_t scratch[8];
-    uint32_t n = *n_ptr;
+    uint32_t n = n_ptr ? *n_ptr : n_bound;
     if (n > n_bound) n = n_bound;
     uint32_t lo, hi;
     scan_range(n, lo, hi);
-    uint32_t sum = 0;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += BLOCK) sum += cnt[i];
-    uint32_t total;
+    uint32_t sum = 0, nonzero = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += BLOCK) {
+        const uint32_t c = cnt[i];
+        sum += c;
+        nonzero += c != 0 ? 1u : 0u;
+    }
+    uint32_t total, total_nz;
     block_excl_scan<BLOCK>(sum, scratch, &total);
-    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+    block_excl_scan<BLOCK>(nonzero, scratch, &total_nz);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = total;
+        partial[kScanBlocks + blockIdx.x] = total_nz;  // second half: how many entries of the slice are non-zero
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_scan_down(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
                                                      const uint32_t* n_ptr, uint32_t n_bound,
-                                                     const uint32_t* partial, uint32_t* total_out) {
+                                                     const uint32_t* partial, uint32_t* total_out,
+                                                     uint32_t* nonzero_out) {
     __shared__ uint32_t scratch[8];
-    uint32_t n = *n_ptr;
+    uint32_t n = n_ptr ? *n_ptr : n_bound;
     if (n > n_bound) n = n_bound;
     uint32_t lo, hi;
     scan_range(n, lo, hi);
@@ -625,6 +644,11 @@ __global__ __launch_bounds__(BLOCK) void k_scan_down(const uint32_t* __restrict_
         block_excl_scan<BLOCK>(mine, scratch, &running);
         block_excl_scan<BLOCK>(p0 + p1, scratch, &grand);
         if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = grand;
+        if (nonzero_out && blockIdx.x == 0) {  // uniform branch
+            uint32_t nz;
+            block_excl_scan<BLOCK>(partial[kScanBlocks + threadIdx.x] + partial[kScanBlocks + BLOCK + threadIdx.x], scratch, &nz);
+            if (threadIdx.x == 0) *nonzero_out = nz;
+        }
     }
     for (uint32_t base = lo; base < hi; base += 1024) {
         const uint32_t i0 = base + threadIdx.x * 4;  // base is 1024-aligned -> 16-byte aligned
@@ -653,9 +677,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan_down(const uint32_t* __restrict_
 }
 
 void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n, uint32_t n_bound,
-                           uint32_t* partial, uint32_t* total_out, hipStream_t s) {
+                           uint32_t* partial, uint32_t* total_out, uint32_t* nonzero_out, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_reduce, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, n, n_bound, partial);
-    hipLaunchKernelGGL(k_scan_down, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, off, n, n_bound, partial, total_out);
+    hipLaunchKernelGGL(k_scan_down, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, off, n, n_bound, partial, total_out,
+                       nonzero_out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -669,21 +694,21 @@ __global__ __launch_bounds__(BLOCK) void k_duplicate(const uint32_t* __restrict_
                                                      uint32_t n_bound, uint32_t tiles_x, int shift, uint32_t capacity,
                                                      uint32_t* __restrict__ inst_tile,
                                                      uint32_t* __restrict__ inst_gid, Counters* counters) {
-    uint32_t n = *n_visible;
+    uint32_t n = n_visible ? *n_visible : n_bound;  // null: every Gaussian, in index order (bin-local path)
     if (n > n_bound) n = n_bound;
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && counters->bin_entries > capacity) counters->overflow = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && counters->bin_entries > capacity) counters->overflow |= 1u;
     if (blockIdx.x * BLOCK >= n) return;
 
     bool valid = j < n;
     uint32_t g = 0, o = 0, cnt = 0;
     ushort4 box = make_ushort4(0, 0, 0, 0);
     if (valid) {
-        g = order[j];
+        g = order ? order[j] : j;
         o = off[j];
         cnt = tiles_sorted[j];
-        box = aabb[g];
+        if (cnt) box = aabb[g];
         if (shift) {  // tile box -> box of (tile >> shift) bins, upper bounds exclusive
             box.z = (unsigned short)(((box.z - 1u) >> shift) + 1u);
             box.w = (unsigned short)(((box.w - 1u) >> shift) + 1u);
@@ -903,7 +928,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin_count(BinArgs a) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     constexpr int SS = 64 * R;
     if (total_chunks > a.max_chunks) {  // chunk table too small: flag, stay in bounds; the frame is re-run
-        if (blockIdx.x == 0 && tid == 0) a.counters->overflow = 1;
+        if (blockIdx.x == 0 && tid == 0) a.counters->overflow |= 1u;
         total_chunks = a.max_chunks;
     }
     // the chunk loop is per wave: tell the compiler its control values are wave-uniform (scalar registers)
@@ -950,6 +975,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scan(BinArgs a) {
     if ((uint32_t)tid == bin) {
         s_first = cpre;
         s_n = nch;
+        atomicMax(&a.counters->max_bin, c);  // the fullest bin: the host picks the depth-order path of later frames by it
     }
     __syncthreads();
     const uint32_t first = min(s_first, a.max_chunks), n = min(s_n, a.max_chunks - first);
@@ -1037,7 +1063,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(BinArgs a) {
     }
     if (threadIdx.x == 0) {
         a.counters->instances = running;
-        if (running > a.capacity) a.counters->overflow = 1;
+        if (running > a.capacity) a.counters->overflow |= 1u;
     }
 }
 
@@ -1086,6 +1112,135 @@ __global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
         s_ids[w][lane] = g;
         bin_walk<R, true>(m, cursor, out, s_ids[w]);  // append, in candidate order
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Depth order INSIDE the bins (the bin-local path).  The candidates of a bin arrive in Gaussian-index order (stable
+// radix pass by bin over candidates emitted in index order); one workgroup per bin orders them by (depth bits, id)
+// entirely in LDS: four stable 8-bit LSD passes over (key, id) pairs that ping-pong between two LDS buffers, no global
+// traffic and no kernel boundary between the passes.  This replaces the twelve kernels of the global depth order.
+// A bin with more than kBinSortMax candidates does not fit: the kernel raises overflow bit 2 and the host re-runs
+// the frame on the global-depth-order path.
+//
+// Element e of the list belongs to wave e / 512, round (e % 512) / 64, lane e % 64, so (wave, round, lane) order is
+// list order; the stable rank inside (wave, digit) comes from wave64 ballot matching as in k_radix_scatter.
+// ---------------------------------------------------------------------------------------
+constexpr int kBinSortThreads = 1024;
+__global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __restrict__ bin_count,
+                                                              const uint32_t* __restrict__ ids_in,
+                                                              const float* __restrict__ depth,
+                                                              uint32_t* __restrict__ ids_out, Counters* counters) {
+    __shared__ uint32_t s_key[2][kBinSortMax];
+    __shared__ uint32_t s_id[2][kBinSortMax];
+    __shared__ uint32_t s_wcnt[16][256];  // per-wave digit counters, then per-wave write cursors
+    __shared__ uint32_t scratch[16];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const uint32_t bin = blockIdx.x;
+    uint32_t c, off;
+    {
+        const uint32_t v = tid < 256 ? bin_count[tid] : 0u;
+        uint32_t all;
+        const uint32_t excl = block_excl_scan<kBinSortThreads>(v, scratch, &all);
+        __shared__ uint32_t s_c, s_o;
+        if ((uint32_t)tid == bin) {
+            s_c = v;
+            s_o = excl;
+        }
+        __syncthreads();
+        c = s_c;
+        off = s_o;
+    }
+    if (c == 0) return;
+    if (c > (uint32_t)kBinSortMax) {
+        if (tid == 0) atomicOr(&counters->overflow, 2u);
+        return;
+    }
+    for (uint32_t e = tid; e < c; e += kBinSortThreads) {
+        const uint32_t g = ids_in[off + e];
+        s_id[0][e] = g;
+        s_key[0][e] = __float_as_uint(depth[g]);
+    }
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t wbase = (uint32_t)w * 512u;
+    const int rounds = wbase >= c ? 0 : (int)min(8u, (c - wbase + 63u) / 64u);  // wave-uniform
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int src = pass & 1, dst = src ^ 1, shift = pass * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_wcnt[(tid >> 8) * 4 + k][tid & 255] = 0;
+        __syncthreads();  // also orders the previous pass's (or the load's) LDS writes before this pass's reads
+        uint32_t key[8], id[8], rank[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            key[r] = 0;
+            id[r] = 0;
+            rank[r] = 0;
+            if (r < rounds) {
+                const uint32_t e = wbase + r * WAVE + lane;
+                const bool ok = e < c;
+                if (ok) {
+                    key[r] = s_key[src][e];
+                    id[r] = s_id[src][e];
+                }
+                const uint32_t d = (key[r] >> shift) & 255u;
+                uint64_t m = __ballot(ok);
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) {
+                    const bool set = (d >> bit) & 1u;
+                    const uint64_t b = __ballot(ok && set);
+                    m &= set ? b : ~b;
+                }
+                uint32_t old = 0;
+                const int leader = m ? (__ffsll((unsigned long long)m) - 1) : 0;
+                if (ok && lane == leader) {
+                    old = s_wcnt[w][d];
+                    s_wcnt[w][d] = old + (uint32_t)__popcll(m);
+                }
+                old = __shfl(old, leader, WAVE);
+                rank[r] = old + (uint32_t)__popcll(m & lt_mask);
+            }
+        }
+        __syncthreads();
+        {   // per digit: prefix over the 16 waves, then exclusive scan over the digits -> per-wave write cursors
+            uint32_t cw[16], cnt = 0;
+            if (tid < 256) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    cw[k] = s_wcnt[k][tid];
+                    cnt += cw[k];
+                }
+            }
+            uint32_t all;
+            uint32_t excl = block_excl_scan<kBinSortThreads>(cnt, scratch, &all);
+            if (tid < 256) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    s_wcnt[k][tid] = excl;
+                    excl += cw[k];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < rounds) {
+                const uint32_t e = wbase + r * WAVE + lane;
+                if (e < c) {
+                    const uint32_t d = (key[r] >> shift) & 255u;
+                    const uint32_t pos = s_wcnt[w][d] + rank[r];
+                    s_key[dst][pos] = key[r];
+                    s_id[dst][pos] = id[r];
+                }
+            }
+        }
+        __syncthreads();  // the cursors in s_wcnt are re-zeroed at the top of the next pass
+    }
+    for (uint32_t e = tid; e < c; e += kBinSortThreads) ids_out[off + e] = s_id[0][e];  // four passes: back in buffer 0
+}
+
+void launch_bin_sort(const uint32_t* bin_count, const uint32_t* ids_in, const float* depth, uint32_t* ids_out,
+                     Counters* counters, uint32_t bins, hipStream_t s) {
+    hipLaunchKernelGGL(k_bin_sort, dim3(bins), dim3(kBinSortThreads), 0, s, bin_count, ids_in, depth, ids_out, counters);
 }
 
 static BinArgs bin_args(const BinLaunch& b) {

@@ -180,7 +180,9 @@ def main():
                                    f"(BASELINE configs[1]; configs[3] when n_gpus>1)",
                        "gaussians": int(st.num_gaussians), "visible": int(st.num_visible),
                        "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries), "tiles": T, "output": "rgba32f" + ("+bgra8" if args.bgra8 else ""),
-                       "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}"},
+                       "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}",
+                       "depth_order_path": {1: "global", 2: "bin-local"}.get(int(st.sort_path), "?"),
+                       "max_bin_entries": int(st.max_bin_entries)},
             # distribution of the per-frame time over the timed region (median + p5/p95), rank 0
             "frame_ms": ({"p5": round(float(np.percentile(intervals, 5)), 4), "p50": round(float(np.percentile(intervals, 50)), 4),
                           "p95": round(float(np.percentile(intervals, 95)), 4), "n": int(len(intervals))}

@@ -73,6 +73,8 @@ typedef struct {
     float ms_total;
     uint32_t retries; /* frames re-run after growing the instance buffers */
     uint32_t num_bin_entries; /* E1: (bin, Gaussian) candidates of the tile binning's first level */
+    uint32_t max_bin_entries; /* candidates in the fullest bin */
+    uint32_t sort_path;       /* depth-order path the frame took: 1 = global, 2 = bin-local (gs_set_sort_path) */
 } gs_frame_stats;
 
 /* Stage taps for parity tests (the role of Buffer::download / assertEquals,
@@ -163,6 +165,15 @@ int gs_set_timing(gs_renderer* r, int enabled);
  * on the GPU.  Frames that may be in flight together must be given distinct output buffers.  An
  * overflowed frame and everything queued behind it are re-run after growing. */
 int gs_set_frames_in_flight(gs_renderer* r, int frames);
+/* How the per-tile lists get their depth order (same lists either way; no reference counterpart -- the reference
+ * sorts all D instances, sort/hist.comp + sort/sort.comp):
+ *   1  global:    the V visible Gaussians are ordered by depth first (12 small kernels), then binned;
+ *   2  bin-local: candidates are binned in index order and every bin is ordered by one workgroup in LDS (one kernel);
+ *                 a bin with more than 8192 candidates does not fit -> GS_ERR_OVERFLOW at the next synchronisation;
+ *   0  automatic (default): bin-local, with a transparent re-run on the global path when a bin does not fit (and back
+ *                 once the bins have fitted again for 32 frames).
+ * The GS_STAGE_DEPTH_ORDER tap exists on path 1 only. */
+int gs_set_sort_path(gs_renderer* r, int mode);
 /* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
  * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
 int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset);

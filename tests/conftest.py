@@ -27,3 +27,18 @@ def gpu(pkg):
     if pkg.device_count() < 1:
         pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
     return 0
+
+
+def pytest_generate_tests(metafunc):
+    """Every GPU test runs on both depth-order paths: the global depth order (GS_SORT_PATH=1, 26 kernels per frame)
+    and the automatic choice (bin-local in-LDS sort, falling back when a bin does not fit)."""
+    if metafunc.definition.get_closest_marker("gpu") and "_sort_path" in metafunc.fixturenames:
+        metafunc.parametrize("_sort_path", ["1", "0"], ids=["global", "auto"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def _sort_path(request, monkeypatch):
+    param = getattr(request, "param", None)
+    if param is not None:
+        monkeypatch.setenv("GS_SORT_PATH", param)
+    return param

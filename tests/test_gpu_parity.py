@@ -303,3 +303,60 @@ def test_frame_intervals_track_completions(pkg, gpu):
     rend.close()
     scene.close()
     hb.close()
+
+
+def _dense_bin_records(pkg, n=20000):
+    rec = pkg.synth.synth_records(n, seed=9, kind="A")
+    rec[:, 0] = rec[:, 0] * 0.02 + 0.3
+    rec[:, 1] = rec[:, 1] * 0.02 - 0.2
+    return rec
+
+
+def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
+    """gs_set_sort_path: the bin-local path (one in-LDS sort per bin) and the global depth order build the same
+    lists; a bin beyond 8192 candidates is an error when the bin-local path is forced and a transparent re-run on the
+    global path in automatic mode; once the bins fit again for 32 frames the automatic mode returns."""
+    monkeypatch.delenv("GS_SORT_PATH", raising=False)
+    w, h = 640, 360
+    # (1) a scene whose bins all fit: both forced paths, stage by stage
+    rec = pkg.synth.synth_records(6000, seed=21, kind="A")
+    verts, u_ref, ref = oracle_frame(oracle, rec, w, h)
+    scene = pkg.Scene.from_records(rec)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    for mode in (2, 1, 0):
+        rend = pkg.Renderer(scene)
+        rend.set_sort_path(mode)
+        img, _ = rend.render_host(u)
+        assert rend.stats().sort_path == (1 if mode == 1 else 2)
+        assert rend.stats().max_bin_entries <= 8192
+        compare_stages(pkg, rend, u, ref)
+        np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+        rend.close()
+    scene.close()
+    # (2) 20 000 splats in one bin
+    rec = _dense_bin_records(pkg)
+    verts, u_ref, ref = oracle_frame(oracle, rec, w, h)
+    scene = pkg.Scene.from_records(rec)
+    rend = pkg.Renderer(scene)
+    rend.set_sort_path(2)
+    with pytest.raises(pkg.GsError) as e:
+        rend.render_host(u)
+    assert e.value.code == -5
+    rend.close()
+    rend = pkg.Renderer(scene)  # automatic
+    img, _ = rend.render_host(u)
+    st = rend.stats()
+    assert st.sort_path == 1 and st.retries >= 1 and st.max_bin_entries > 8192
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+    # (3) the camera turns away from the dense bin: after 32 fitting frames the bin-local path is back
+    away = pkg.make_camera(rotation=(0.0, 0.0, 1.0, 0.0))  # looking down +z: nothing in view
+    ua = pkg.camera_uniforms(away, w, h)
+    for _ in range(40):
+        rend.render_host(ua)
+    assert rend.stats().sort_path == 2
+    img2, _ = rend.render_host(u)  # back at the dense bin: falls back again, same image
+    assert rend.stats().sort_path == 1
+    np.testing.assert_array_equal(img2.view(np.uint32), ref["image"].view(np.uint32))
+    rend.close()
+    scene.close()
