@@ -1122,8 +1122,8 @@ __global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
 // A bin with more than kBinSortMax candidates does not fit: the kernel raises overflow bit 2 and the host re-runs
 // the frame on the global-depth-order path.
 //
-// Element e of the list belongs to wave e / 512, round (e % 512) / 64, lane e % 64, so (wave, round, lane) order is
-// list order; the stable rank inside (wave, digit) comes from wave64 ballot matching as in k_radix_scatter.
+// (wave, round, lane) order is list order; the stable rank inside (wave, digit) comes from wave64 ballot matching as
+// in k_radix_scatter.
 // ---------------------------------------------------------------------------------------
 constexpr int kBinSortThreads = 1024;
 __global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __restrict__ bin_count,
@@ -1161,8 +1161,9 @@ __global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __
         s_key[0][e] = __float_as_uint(depth[g]);
     }
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const uint32_t wbase = (uint32_t)w * 512u;
-    const int rounds = wbase >= c ? 0 : (int)min(8u, (c - wbase + 63u) / 64u);  // wave-uniform
+    // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64: all 16 waves share the work
+    const int rounds = (int)((c + kBinSortThreads - 1) / kBinSortThreads);  // block-uniform, <= 8
+    const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
 #pragma unroll 1
     for (int pass = 0; pass < 4; ++pass) {
         const int src = pass & 1, dst = src ^ 1, shift = pass * 8;
@@ -1183,13 +1184,18 @@ __global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __
                     id[r] = s_id[src][e];
                 }
                 const uint32_t d = (key[r] >> shift) & 255u;
-                uint64_t m = __ballot(ok);
+                // lanes holding a valid key with my digit: AND over the bits of (ballot(bit) XNOR my bit), in 32-bit halves
+                const uint64_t okm = __ballot(ok);
+                uint32_t mlo = (uint32_t)okm, mhi = (uint32_t)(okm >> 32);
 #pragma unroll
                 for (int bit = 0; bit < 8; ++bit) {
-                    const bool set = (d >> bit) & 1u;
-                    const uint64_t b = __ballot(ok && set);
-                    m &= set ? b : ~b;
+                    const uint32_t mine = (d >> bit) & 1u;
+                    const uint64_t b = __builtin_amdgcn_ballot_w64(mine != 0);
+                    const uint32_t splat = 0u - mine;
+                    mlo &= ~((uint32_t)b ^ splat);
+                    mhi &= ~((uint32_t)(b >> 32) ^ splat);
                 }
+                const uint64_t m = ((uint64_t)mhi << 32) | mlo;
                 uint32_t old = 0;
                 const int leader = m ? (__ffsll((unsigned long long)m) - 1) : 0;
                 if (ok && lane == leader) {
