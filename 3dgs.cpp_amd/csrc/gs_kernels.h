@@ -43,7 +43,7 @@ struct Counters {
     uint32_t max_bin;    // candidates in the fullest bin
     uint32_t pad;
 };
-constexpr int kBinSortMax = 8192;  // candidates per bin that k_bin_sort can order in LDS (2 x 64 KiB of (key, id))
+constexpr int kBinSortMax = 16384;  // candidates per bin that k_bin_sort can order in LDS (128 KiB of (key, id))
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s);
 // counters (nullable): the kernel clears counters->overflow, so that a frame needs no memset node.

@@ -1117,8 +1117,8 @@ __global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
 // ---------------------------------------------------------------------------------------
 // Depth order INSIDE the bins (the bin-local path).  The candidates of a bin arrive in Gaussian-index order (stable
 // radix pass by bin over candidates emitted in index order); one workgroup per bin orders them by (depth bits, id)
-// entirely in LDS: four stable 8-bit LSD passes over (key, id) pairs that ping-pong between two LDS buffers, no global
-// traffic and no kernel boundary between the passes.  This replaces the twelve kernels of the global depth order.
+// entirely in LDS: four stable 8-bit LSD passes over (key, id) pairs, no global traffic and no kernel boundary
+// between the passes.  This replaces the twelve kernels of the global depth order.
 // A bin with more than kBinSortMax candidates does not fit: the kernel raises overflow bit 2 and the host re-runs
 // the frame on the global-depth-order path.
 //
@@ -1130,8 +1130,10 @@ __global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __
                                                               const uint32_t* __restrict__ ids_in,
                                                               const float* __restrict__ depth,
                                                               uint32_t* __restrict__ ids_out, Counters* counters) {
-    __shared__ uint32_t s_key[2][kBinSortMax];
-    __shared__ uint32_t s_id[2][kBinSortMax];
+    // ONE (key, id) buffer: between the ranking and the scatter of a pass every element lives in registers (two
+    // barriers apart), so a pass scatters back into the buffer it read -- 16 384 entries in 128 KiB
+    __shared__ uint32_t s_key[kBinSortMax];
+    __shared__ uint32_t s_id[kBinSortMax];
     __shared__ uint32_t s_wcnt[16][256];  // per-wave digit counters, then per-wave write cursors
     __shared__ uint32_t scratch[16];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
@@ -1157,22 +1159,23 @@ __global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __
     }
     for (uint32_t e = tid; e < c; e += kBinSortThreads) {
         const uint32_t g = ids_in[off + e];
-        s_id[0][e] = g;
-        s_key[0][e] = __float_as_uint(depth[g]);
+        s_id[e] = g;
+        s_key[e] = __float_as_uint(depth[g]);
     }
+    constexpr int kRounds = kBinSortMax / kBinSortThreads;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64: all 16 waves share the work
-    const int rounds = (int)((c + kBinSortThreads - 1) / kBinSortThreads);  // block-uniform, <= 8
+    const int rounds = (int)((c + kBinSortThreads - 1) / kBinSortThreads);  // block-uniform, <= kRounds
     const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
 #pragma unroll 1
     for (int pass = 0; pass < 4; ++pass) {
-        const int src = pass & 1, dst = src ^ 1, shift = pass * 8;
+        const int shift = pass * 8;
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_wcnt[(tid >> 8) * 4 + k][tid & 255] = 0;
         __syncthreads();  // also orders the previous pass's (or the load's) LDS writes before this pass's reads
-        uint32_t key[8], id[8], rank[8];
+        uint32_t key[kRounds], id[kRounds], rank[kRounds];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < kRounds; ++r) {
             key[r] = 0;
             id[r] = 0;
             rank[r] = 0;
@@ -1180,8 +1183,8 @@ __global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __
                 const uint32_t e = wbase + r * WAVE + lane;
                 const bool ok = e < c;
                 if (ok) {
-                    key[r] = s_key[src][e];
-                    id[r] = s_id[src][e];
+                    key[r] = s_key[e];
+                    id[r] = s_id[e];
                 }
                 const uint32_t d = (key[r] >> shift) & 255u;
                 // lanes holding a valid key with my digit: AND over the bits of (ballot(bit) XNOR my bit), in 32-bit halves
@@ -1228,20 +1231,20 @@ __global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < kRounds; ++r) {
             if (r < rounds) {
                 const uint32_t e = wbase + r * WAVE + lane;
                 if (e < c) {
                     const uint32_t d = (key[r] >> shift) & 255u;
                     const uint32_t pos = s_wcnt[w][d] + rank[r];
-                    s_key[dst][pos] = key[r];
-                    s_id[dst][pos] = id[r];
+                    s_key[pos] = key[r];
+                    s_id[pos] = id[r];
                 }
             }
         }
         __syncthreads();  // the cursors in s_wcnt are re-zeroed at the top of the next pass
     }
-    for (uint32_t e = tid; e < c; e += kBinSortThreads) ids_out[off + e] = s_id[0][e];  // four passes: back in buffer 0
+    for (uint32_t e = tid; e < c; e += kBinSortThreads) ids_out[off + e] = s_id[e];
 }
 
 void launch_bin_sort(const uint32_t* bin_count, const uint32_t* ids_in, const float* depth, uint32_t* ids_out,

@@ -169,7 +169,7 @@ int gs_set_frames_in_flight(gs_renderer* r, int frames);
  * sorts all D instances, sort/hist.comp + sort/sort.comp):
  *   1  global:    the V visible Gaussians are ordered by depth first (12 small kernels), then binned;
  *   2  bin-local: candidates are binned in index order and every bin is ordered by one workgroup in LDS (one kernel);
- *                 a bin with more than 8192 candidates does not fit -> GS_ERR_OVERFLOW at the next synchronisation;
+ *                 a bin with more than 16384 candidates does not fit -> GS_ERR_OVERFLOW at the next synchronisation;
  *   0  automatic (default): bin-local, with a transparent re-run on the global path when a bin does not fit (and back
  *                 once the bins have fitted again for 32 frames).
  * The GS_STAGE_DEPTH_ORDER tap exists on path 1 only. */

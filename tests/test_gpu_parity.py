@@ -314,7 +314,7 @@ def _dense_bin_records(pkg, n=20000):
 
 def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
     """gs_set_sort_path: the bin-local path (one in-LDS sort per bin) and the global depth order build the same
-    lists; a bin beyond 8192 candidates is an error when the bin-local path is forced and a transparent re-run on the
+    lists; a bin beyond 16384 candidates is an error when the bin-local path is forced and a transparent re-run on the
     global path in automatic mode; once the bins fit again for 32 frames the automatic mode returns."""
     monkeypatch.delenv("GS_SORT_PATH", raising=False)
     w, h = 640, 360
@@ -328,7 +328,7 @@ def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
         rend.set_sort_path(mode)
         img, _ = rend.render_host(u)
         assert rend.stats().sort_path == (1 if mode == 1 else 2)
-        assert rend.stats().max_bin_entries <= 8192
+        assert rend.stats().max_bin_entries <= 16384
         compare_stages(pkg, rend, u, ref)
         np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
         rend.close()
@@ -346,7 +346,7 @@ def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
     rend = pkg.Renderer(scene)  # automatic
     img, _ = rend.render_host(u)
     st = rend.stats()
-    assert st.sort_path == 1 and st.retries >= 1 and st.max_bin_entries > 8192
+    assert st.sort_path == 1 and st.retries >= 1 and st.max_bin_entries > 16384
     compare_stages(pkg, rend, u, ref)
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
     # (3) the camera turns away from the dense bin: after 32 fitting frames the bin-local path is back
@@ -358,5 +358,24 @@ def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
     img2, _ = rend.render_host(u)  # back at the dense bin: falls back again, same image
     assert rend.stats().sort_path == 1
     np.testing.assert_array_equal(img2.view(np.uint32), ref["image"].view(np.uint32))
+    rend.close()
+    scene.close()
+
+
+def test_bin_local_sort_at_its_capacity(pkg, oracle, gpu, monkeypatch):
+    """A bin with 9 000-16 000 candidates (more than one 8-round batch per wave) still takes the bin-local path."""
+    monkeypatch.delenv("GS_SORT_PATH", raising=False)
+    rec = _dense_bin_records(pkg, n=13000)
+    w, h = 640, 360
+    verts, u_ref, ref = oracle_frame(oracle, rec, w, h)
+    scene = pkg.Scene.from_records(rec)
+    rend = pkg.Renderer(scene)
+    rend.set_sort_path(2)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    img, _ = rend.render_host(u)
+    st = rend.stats()
+    assert st.sort_path == 2 and 8192 < st.max_bin_entries <= 16384
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
     rend.close()
     scene.close()
