@@ -30,19 +30,25 @@ import __graft_entry__ as entry  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def algorithmic_bytes(n, v, d, e1, t, p):
+def algorithmic_bytes(n, v, d, e1, t, p, bin_local=True):
     """Implementation-independent HBM bytes per frame and pass for this decomposition.
-    n Gaussians, v visible, d tile instances, e1 (bin, Gaussian) candidates, t tiles, p pixels."""
+    n Gaussians, v visible, d tile instances, e1 (bin, Gaussian) candidates, t tiles, p pixels.
+    bin_local: the depth order is taken inside the bins (k_bin_sort) instead of by four global passes over V."""
+    if bin_local:
+        pre_extra, scan_items, dup_items = 4 * n, n, n            # bins-per-Gaussian plane out; scan / emit over all N
+        order = (4 + 4 + 4) * e1                                  # k_bin_sort: id in, depth gathered, id out
+    else:
+        pre_extra, scan_items, dup_items = 0, v, v
+        order = 4 * (4 + 16) * v                                  # 4 passes over V: histogram read 4 + (key, id) in 8 + out 8
     return {
         # pos 12 + cov3d 24 per Gaussian; opacity 4 + SH 192 per visible; 52 B of attributes out; tiles 4
-        "preprocess": n * (12 + 24) + v * (4 + 192) + v * 52 + n * 4,
+        "preprocess": n * (12 + 24) + v * (4 + 192) + v * 52 + n * 4 + pre_extra,
         # bins-per-Gaussian in, offsets out
-        "prefix_sum": 8 * v,
-        # level-1 emit: id, offset, count, box per visible; (bin, id) per candidate
-        "preprocess_sort": v * 20 + e1 * 8,
-        # depth order: 4 passes over V (histogram read 4 + key/id in 8 + out 8); one pass over the E1 candidates;
-        # fill: candidate id 4 + box 8 in, Gaussian id 4 out per instance
-        "sort": 4 * (4 + 16) * v + (4 + 16) * e1 + 12 * e1 + 4 * d,
+        "prefix_sum": 8 * scan_items,
+        # level-1 emit: count + offset per item, id + box per visible; (bin, id) per candidate
+        "preprocess_sort": 8 * dup_items + 12 * v + e1 * 8,
+        # depth order; one pass over the E1 candidates by bin; fill: candidate id 4 + box 8 in, Gaussian id 4 out per instance
+        "sort": order + (4 + 16) * e1 + 12 * e1 + 4 * d,
         # per-tile counts: candidate id + box in; tile totals and ranges out
         "tile_boundary": 12 * e1 + 12 * t,
         "render": 40 * d + 16 * p,
@@ -153,7 +159,8 @@ def main():
     if rank == 0:
         fps = world * args.steps / elapsed
         T = ((w + 15) // 16) * ((h + 15) // 16)
-        nbytes = algorithmic_bytes(st.num_gaussians, st.num_visible, st.num_instances, st.num_bin_entries, T, w * h)
+        nbytes = algorithmic_bytes(st.num_gaussians, st.num_visible, st.num_instances, st.num_bin_entries, T, w * h,
+                                   bin_local=int(st.sort_path) == 2)
         names = ["preprocess", "prefix_sum", "preprocess_sort", "sort", "tile_boundary", "render"]
         ms = {k: getattr(sums, "ms_" + k) / max(frames, 1) for k in names}
         per_pass = {k: {"ms": round(ms[k], 4), "alg_MB": round(nbytes[k] / 1e6, 2),
