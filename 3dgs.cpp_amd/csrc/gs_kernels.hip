@@ -1313,23 +1313,26 @@ void launch_bin_fill(const BinLaunch& b, hipStream_t s) {
 
 // min over the pixel rectangle [xa,xb] x [ya,yb] of q(d) = 0.5 (c00 dx^2 + c11 dy^2) + c01 dx dy,
 // d = uv - pixel.  q is convex with its minimum 0 at d = 0: inside the rectangle the answer is 0,
-// otherwise the minimum lies on one of the four edges, where q is a 1-D parabola.
+// otherwise the minimum lies on an edge facing the centre, where q is a 1-D parabola.
 __device__ __forceinline__ float min_q_rect(float c00, float c01, float c11, float u, float v, float xa,
                                             float xb, float ya, float yb) {
     const float dx_lo = u - xb, dx_hi = u - xa, dy_lo = v - yb, dy_hi = v - ya;
-    if (!(dx_lo > 0.0f) && !(dx_hi < 0.0f) && !(dy_lo > 0.0f) && !(dy_hi < 0.0f)) return 0.0f;
+    const bool in_x = !(dx_lo > 0.0f) && !(dx_hi < 0.0f), in_y = !(dy_lo > 0.0f) && !(dy_hi < 0.0f);  // NaN -> inside
+    // This is a bound, not part of the pipeline's arithmetic: FMAs are welcome (the caller's slack covers rounding).
+    // q(a, t) = h00 a^2 + t (h11 t + c01 a) with h = c / 2.  Only the edges that face the centre can hold the minimum
+    // (a segment from the centre to a point of a far edge crosses a near edge, where the convex q is smaller): at most
+    // one vertical and one horizontal edge; on an edge one coordinate is fixed and the other is the parabola's
+    // minimiser r * fixed, clamped to the edge.
+    const float h00 = 0.5f * c00, h11 = 0.5f * c11;
     const float r11 = -c01 * __builtin_amdgcn_rcpf(c11), r00 = -c01 * __builtin_amdgcn_rcpf(c00);
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float a = e ? dx_hi : dx_lo;  // vertical edges: dx fixed, parabola in dy
-        const float t = fminf(fmaxf(r11 * a, dy_lo), dy_hi);
-        best = fminf(best, 0.5f * (c00 * a * a + c11 * t * t) + c01 * a * t);
-        const float b = e ? dy_hi : dy_lo;  // horizontal edges: dy fixed, parabola in dx
-        const float s = fminf(fmaxf(r00 * b, dx_lo), dx_hi);
-        best = fminf(best, 0.5f * (c00 * s * s + c11 * b * b) + c01 * s * b);
-    }
-    return best;  // any point of an edge bounds the true minimum from above: an inexact rcp only loosens the test
+    const float a = dx_lo > 0.0f ? dx_lo : dx_hi;  // the vertical edge nearer to the centre: dx fixed, parabola in dy
+    const float t = fminf(fmaxf(r11 * a, dy_lo), dy_hi);
+    const float qv = __builtin_fmaf(t, __builtin_fmaf(h11, t, c01 * a), h00 * a * a);
+    const float b = dy_lo > 0.0f ? dy_lo : dy_hi;  // the horizontal edge nearer to the centre
+    const float s = fminf(fmaxf(r00 * b, dx_lo), dx_hi);
+    const float qh = __builtin_fmaf(s, __builtin_fmaf(h00, s, c01 * b), h11 * b * b);
+    // any point of an edge bounds the true minimum from above: an inexact rcp only loosens the test
+    return in_x ? (in_y ? 0.0f : qh) : (in_y ? qv : fminf(qv, qh));
 }
 
 #ifdef GS_BLEND_STATS
