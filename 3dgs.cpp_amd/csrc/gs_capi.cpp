@@ -750,7 +750,7 @@ struct gs_renderer {
         }
 
         // ---- blend ----
-        gs::launch_blend(ranges.p, sorted_gid, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, num_sets > 1 ? 16384u : 0u, cnt,
+        gs::launch_blend(ranges.p, sorted_gid, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
                          fused_counters ? sl.h_counters : nullptr, stream);
         HIP_CHECK(hipEventRecord(ev[7], stream));
         if (!fused_counters) HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));

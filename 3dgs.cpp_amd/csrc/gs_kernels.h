@@ -112,13 +112,11 @@ struct BinLaunch {
 void launch_bin_ranges(const BinLaunch& b, hipStream_t s);  // k_bin_count, k_bin_scan, k_tile_scan
 void launch_bin_fill(const BinLaunch& b, hipStream_t s);    // k_bin_fill
 
-// render.comp counterpart.  lds_pad bytes of unused dynamic LDS cap the kernel's residency: with several
-// frames in flight, 16 KiB (4 instead of 8 workgroups per CU) leaves wave slots for the other frames'
-// latency-bound passes, which is worth ~4 % of throughput; 0 when frames run one at a time.
+// render.comp counterpart.
 // tile_order[b] = the tile workgroup b renders (a permutation of the tiles)
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
-                  uint32_t height, float* rgba, uint8_t* bgra, uint32_t lds_pad, const Counters* counters,
+                  uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
                   Counters* host_counters /* pinned, nullable: *host_counters = *counters */, hipStream_t s);
 
 }  // namespace gs

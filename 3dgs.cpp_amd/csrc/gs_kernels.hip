@@ -1501,12 +1501,11 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
 
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
-                  uint32_t height, float* rgba, uint8_t* bgra, uint32_t lds_pad, const Counters* counters,
+                  uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
                   Counters* host_counters, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
-    // lds_pad: unused dynamic LDS that only lowers the kernel's residency (see gs_kernels.h)
-    hipLaunchKernelGGL(k_blend, dim3(tx * ty), dim3(BLOCK), lds_pad, s, reinterpret_cast<const uint2*>(ranges),
+    hipLaunchKernelGGL(k_blend, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                        sorted_gid, tile_order, av.conic_op, av.uv_rg, av.b, width, height, tx,
                        reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters);
 }
