@@ -1,14 +1,17 @@
 """Seeded random sweep: scene size, splat size, opacity, framebuffer size, camera pose and field of view.
 Every case compares the per-tile lists, the ranges and the fp32 image with the oracle (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+SEEDS = int(os.environ.get("GS_FUZZ_SEEDS", 40))  # soak: GS_FUZZ_SEEDS=160 (seeds >= 40 draw scenes of up to 400 k Gaussians)
 
 
 def _case(seed):
     rng = np.random.default_rng(seed)
-    n = int(rng.choice([0, 1, 7, 300, 2500, 9000, 20000]))
+    n = int(rng.choice([0, 1, 7, 300, 2500, 9000, 20000] if seed < 40 else [20000, 60000, 150000, 400000]))
     w = int(rng.integers(1, 1300))
     h = int(rng.integers(1, 800))
     log_scale = float(rng.uniform(-5.5, -1.0))
@@ -20,7 +23,7 @@ def _case(seed):
     return n, w, h, log_scale, tuple(q), tuple(pos), fov, float(rng.uniform(-3, 6))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(SEEDS))
 def test_random_case(pkg, oracle, gpu, seed):
     n, w, h, log_scale, q, pos, fov, opacity_shift = _case(seed)
     rec = pkg.synth.synth_records(n, seed=1000 + seed, kind="A", log_scale_mean=log_scale)
