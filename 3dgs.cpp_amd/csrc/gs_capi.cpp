@@ -4,8 +4,9 @@
 // draw (src/Renderer.cpp:468-529, 532-717, 366-426): every pass is enqueued on one HIP stream with
 // grids that do not depend on the data-dependent counts V (visible) and D (instances); the counts
 // live in device memory, so the reference's mid-frame fence wait + 4-byte readback + command-buffer
-// re-record (Renderer.cpp:391-399, 538) disappears.  D is copied back asynchronously at the end of
-// the frame only to detect instance-buffer overflow (Renderer.cpp:541-563 grows and retries too).
+// re-record (Renderer.cpp:391-399, 538) disappears.  The frame's last kernel publishes the counters to
+// pinned memory only to detect instance-buffer overflow (Renderer.cpp:541-563 grows and retries too)
+// or a bin that outgrew the bin-local depth order (then the frame is re-run on the global path).
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -425,7 +426,7 @@ void load_ply_streamed(gs_scene* s, const std::string& path) {
 // gs_renderer
 // ------------------------------------------------------------------------------------------
 // One complete set of per-frame device buffers + the stream its passes run on.  Frames alternate between
-// sets, so with >= 2 sets the small launch-bound passes of frame i+1 (depth order, scans) overlap the
+// sets, so with >= 2 sets the small launch-bound passes of frame i+1 (scans, binning) overlap the
 // VALU-bound blend of frame i on the same GPU.
 struct FrameBuffers {
     hipStream_t stream = nullptr;
@@ -511,7 +512,7 @@ struct gs_renderer {
     gs_frame_stats last{};  // stats of the most recently retired frame
 
     // Which depth-order path a frame takes: bin-local = one in-LDS sort per bin after the binning
-    // (13 kernels per frame), global = the V visible Gaussians ordered first (26 kernels; any bin size).
+    // (14 kernels per frame), global = the V visible Gaussians ordered first (26 kernels; any bin size).
     // sort_mode 0 = automatic: bin-local unless the fullest bin of a recent frame does not fit k_bin_sort.
     int sort_mode = 0;           // 0 auto, 1 global depth order, 2 bin-local (forced: a bin that does not fit is an error)
     bool bin_local_ok = true;    // automatic mode: no recent frame had a bin beyond kBinSortMax
