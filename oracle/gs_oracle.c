@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <immintrin.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -690,6 +691,96 @@ static double now_ms(void) {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+/* ---- eight pixels per step (AVX2 + FMA): the CPU BASELINE's blend ------------------------------------------------
+ * Same operations in the same order as gso_render, lane by lane (explicit FMAs where gso_render has them, separate
+ * multiplies and adds elsewhere: -ffp-contract=off holds for intrinsics too), with masks where the scalar code has
+ * `continue` / `break`.  gso_render stays the parity checker; tests require the two to agree bit for bit. */
+static inline __m256 gso_exp8(__m256 x) {
+    const __m256 L2E = _mm256_set1_ps(1.44269502162933349609375f), MAGIC = _mm256_set1_ps(12582912.0f);
+    x = _mm256_max_ps(x, _mm256_set1_ps(-87.0f)); /* second operand on NaN, like fmaxf(NaN, -87) */
+    x = _mm256_min_ps(x, _mm256_set1_ps(88.0f));
+    __m256 tm = _mm256_fmadd_ps(x, L2E, MAGIC);
+    __m256 n = _mm256_sub_ps(tm, MAGIC);
+    __m256 f = _mm256_fmsub_ps(x, L2E, n); /* fma(x, L2E, -n) */
+    __m256 p = _mm256_set1_ps(0x1.41d332p-13f);
+    p = _mm256_fmadd_ps(p, f, _mm256_set1_ps(0x1.5f456ap-10f));
+    p = _mm256_fmadd_ps(p, f, _mm256_set1_ps(0x1.3b2dbcp-7f));
+    p = _mm256_fmadd_ps(p, f, _mm256_set1_ps(0x1.c6aed4p-5f));
+    p = _mm256_fmadd_ps(p, f, _mm256_set1_ps(0x1.ebfbdap-3f));
+    p = _mm256_fmadd_ps(p, f, _mm256_set1_ps(0x1.62e430p-1f));
+    p = _mm256_fmadd_ps(p, f, _mm256_set1_ps(1.0f));
+    __m256i pb = _mm256_add_epi32(_mm256_castps_si256(p), _mm256_slli_epi32(_mm256_castps_si256(tm), 23));
+    return _mm256_castsi256_ps(pb);
+}
+
+void gso_render_simd(const gso_vertex_attr* attr, const uint32_t* boundaries, const uint32_t* payload,
+                     uint32_t width, uint32_t height, float* rgba) {
+    const uint32_t tiles_width = (width + 16 - 1) / 16;
+    const uint32_t tiles_height = (height + 16 - 1) / 16;
+    const __m256 lane = _mm256_setr_ps(0, 1, 2, 3, 4, 5, 6, 7);
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int64_t ty = 0; ty < (int64_t)tiles_height; ++ty)
+        for (int64_t tx = 0; tx < (int64_t)tiles_width; ++tx) {
+            const uint32_t start = boundaries[(tx + ty * tiles_width) * 2];
+            const uint32_t end = boundaries[(tx + ty * tiles_width) * 2 + 1];
+            for (uint32_t ly = 0; ly < 16; ++ly) {
+                const uint32_t py = (uint32_t)ty * 16 + ly;
+                if (py >= height) continue;
+                for (uint32_t half = 0; half < 2; ++half) {
+                    const uint32_t px0 = (uint32_t)tx * 16 + half * 8;
+                    if (px0 >= width) continue;
+                    const __m256 fpx = _mm256_add_ps(_mm256_set1_ps((float)px0), lane); /* exact: small integers */
+                    const __m256 fpy = _mm256_set1_ps((float)py);
+                    /* lanes inside the image and not yet past their `break` */
+                    __m256 active = _mm256_cmp_ps(fpx, _mm256_set1_ps((float)width), _CMP_LT_OQ);
+                    __m256 T = _mm256_set1_ps(1.0f), c0 = _mm256_setzero_ps(), c1 = c0, c2 = c0;
+                    for (uint32_t i = start; i < end && _mm256_movemask_ps(active); ++i) {
+                        const gso_vertex_attr* a = attr + payload[i];
+                        const float* co = a->conic_opacity;
+                        const __m256 dx = _mm256_sub_ps(_mm256_set1_ps(a->uv[0]), fpx);
+                        const __m256 dy = _mm256_sub_ps(_mm256_set1_ps(a->uv[1]), fpy);
+                        const __m256 s = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(co[2]), dy), dy,
+                                                         _mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(co[0]), dx), dx));
+                        const __m256 nb = _mm256_xor_ps(_mm256_mul_ps(_mm256_set1_ps(co[1]), dx), _mm256_set1_ps(-0.0f));
+                        const __m256 power = _mm256_fmadd_ps(nb, dy, _mm256_mul_ps(_mm256_set1_ps(-0.5f), s));
+                        /* !(power > 0 || power != power)  ==  power <= 0, ordered */
+                        __m256 m = _mm256_and_ps(active, _mm256_cmp_ps(power, _mm256_setzero_ps(), _CMP_LE_OQ));
+                        if (!_mm256_movemask_ps(m)) continue;
+                        /* fminf(0.99f, x): the other operand when x is NaN */
+                        const __m256 alpha = _mm256_min_ps(_mm256_mul_ps(_mm256_set1_ps(co[3]), gso_exp8(power)),
+                                                           _mm256_set1_ps(0.99f));
+                        m = _mm256_andnot_ps(_mm256_cmp_ps(alpha, _mm256_set1_ps(1.0f / 255.0f), _CMP_LT_OQ), m);
+                        const __m256 test_T = _mm256_mul_ps(T, _mm256_sub_ps(_mm256_set1_ps(1.0f), alpha));
+                        const __m256 brk = _mm256_and_ps(m, _mm256_cmp_ps(test_T, _mm256_set1_ps(0.0001f), _CMP_LT_OQ));
+                        const __m256 upd = _mm256_andnot_ps(brk, m);
+                        const __m256 n0 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[0]), alpha), T, c0);
+                        const __m256 n1 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[1]), alpha), T, c1);
+                        const __m256 n2 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[2]), alpha), T, c2);
+                        c0 = _mm256_blendv_ps(c0, n0, upd);
+                        c1 = _mm256_blendv_ps(c1, n1, upd);
+                        c2 = _mm256_blendv_ps(c2, n2, upd);
+                        T = _mm256_blendv_ps(T, test_T, upd);
+                        active = _mm256_andnot_ps(brk, active);
+                    }
+                    float r[8], g[8], b[8];
+                    _mm256_storeu_ps(r, c0);
+                    _mm256_storeu_ps(g, c1);
+                    _mm256_storeu_ps(b, c2);
+                    for (uint32_t k = 0; k < 8 && px0 + k < width; ++k) {
+                        float* o = rgba + ((uint64_t)py * width + px0 + k) * 4;
+                        o[0] = r[k];
+                        o[1] = g[k];
+                        o[2] = b[k];
+                        o[3] = 1.0f;
+                    }
+                }
+            }
+        }
+}
+
+static int g_simd_blend = 0;
+void gso_set_simd_blend(int on) { g_simd_blend = on != 0; }
+
 int gso_render_frame(const gso_vertex* v, const float* cov3d, uint64_t n, const gso_uniforms* u,
                      float* rgba, gso_stats* stats) {
     const uint32_t tile_x = (u->width + 15) / 16, tile_y = (u->height + 15) / 16;
@@ -720,7 +811,7 @@ int gso_render_frame(const gso_vertex* v, const float* cov3d, uint64_t n, const 
     double t4 = now_ms();
     gso_tile_boundary(keys, d, bounds, T);
     double t5 = now_ms();
-    if (rgba) gso_render(attr, bounds, payload, u->width, u->height, rgba);
+    if (rgba) (g_simd_blend ? gso_render_simd : gso_render)(attr, bounds, payload, u->width, u->height, rgba);
     double t6 = now_ms();
     st.ms[0] = t1 - t0;
     st.ms[1] = t2 - t1;

@@ -118,6 +118,13 @@ void gso_tile_boundary(const uint64_t* keys, uint64_t d, uint32_t* boundaries, u
 void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const uint32_t* payload,
                 uint32_t width, uint32_t height, float* rgba);
 
+/* The same blend, eight pixels per step with AVX2 + FMA intrinsics: every lane performs gso_render's operations in
+ * gso_render's order, so the two agree bit for bit (tests/test_oracle_kat.py).  It exists for the CPU BASELINE only
+ * (bench.py): gso_render stays the parity checker.  gso_set_simd_blend(1) makes gso_render_frame use it. */
+void gso_render_simd(const gso_vertex_attr* attr, const uint32_t* boundaries, const uint32_t* payload,
+                     uint32_t width, uint32_t height, float* rgba);
+void gso_set_simd_blend(int on);
+
 /* Whole frame, Renderer::draw order (Renderer.cpp:366-426).  rgba may be
  * NULL.  Uses OpenMP threads when built with -fopenmp (gso_num_threads()).
  * Returns 0, or -1 on allocation failure. */

@@ -130,10 +130,17 @@ def tile_boundary(keys, num_tiles):
     return out
 
 
-def render(attr, boundaries, payload, width, height):
+def render(attr, boundaries, payload, width, height, simd=False):
+    """render.comp restated; simd=True: the AVX2 variant used for the CPU baseline (bit-identical by test)."""
     rgba = np.zeros((height, width, 4), np.float32)
-    lib().gso_render(_p(attr), _p(boundaries), _p(payload), C.c_uint32(width), C.c_uint32(height), _p(rgba))
+    fn = lib().gso_render_simd if simd else lib().gso_render
+    fn(_p(attr), _p(boundaries), _p(payload), C.c_uint32(width), C.c_uint32(height), _p(rgba))
     return rgba
+
+
+def set_simd_blend(on):
+    """render_frame uses the AVX2 blend (CPU baseline timing only; the parity checks use the scalar one)."""
+    lib().gso_set_simd_blend(C.c_int(int(on)))
 
 
 def render_frame(verts, cov, uniforms, want_image=True):

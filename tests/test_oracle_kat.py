@@ -221,3 +221,22 @@ def test_bgra8_pack(oracle):
     out = oracle.pack_bgra8(rgba)
     np.testing.assert_array_equal(out[0, 0], [255, 128, 0, 255])
     np.testing.assert_array_equal(out[0, 1], [64, 255, 0, 255])
+
+
+def test_simd_blend_is_bit_identical_to_the_scalar_checker(pkg, oracle):
+    """gso_render_simd (AVX2, the CPU baseline's blend) must equal gso_render (the parity checker) bit for bit,
+    also on ragged sizes and with non-finite inputs."""
+    import __graft_entry__ as entry
+    synth = entry.load_package().synth
+    for n, w, h, seed, poison in [(6000, 256, 256, 0, False), (2500, 333, 177, 5, True), (9000, 130, 61, 9, False)]:
+        rec = synth.synth_records(n, seed=seed, kind="A")
+        if poison:
+            rec[::50, 54] = np.nan
+            rec[::77, 0] = np.inf
+            rec[::91, 55] = np.nan
+        verts = oracle.activate_records(rec)
+        st = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), w, h))
+        a = oracle.render(st["attr"], st["boundaries"], st["sorted_payload"], w, h)
+        b = oracle.render(st["attr"], st["boundaries"], st["sorted_payload"], w, h, simd=True)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        np.testing.assert_array_equal(a.view(np.uint32), st["image"].view(np.uint32))
