@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Builds oracle/_ref/libgs_ref.so: the REFERENCE'S OWN compute shaders, compiled for the CPU.
+
+TEST INFRASTRUCTURE ONLY -- the checker the restated oracle (gs_oracle.c) is pinned against.
+
+The reference cannot be built here (no Vulkan loader/ICD, no glslang, no glm), but its arithmetic is all in
+GLSL text under /root/reference/src/shaders/.  This script reads that text where it lies (nothing is copied into
+the repository; generated sources live in a temporary directory and only the .so lands in oracle/_ref/, which
+is git-ignored), rewrites what C++ cannot parse, and compiles each shader's main() against
+oracle/glsl_cpu/glsl_compat.hpp with g++ -ffp-contract=off.  The rewrites are purely syntactic:
+
+  1. `#include "./common.glsl"` is replaced by that file's text; `#version` / `#extension` lines are dropped.
+  2. resource declarations become globals of the same names:
+       layout(...) [readonly|writeonly] buffer B { T name[]; };   ->  static buffer<T> name;
+       layout(...) uniform B { members };  (UBO and push constants) ->  static <member>;  for each member
+       layout(...) uniform writeonly image2D name;                 ->  static image2D name;
+       layout(local_size_x = X, local_size_y = Y, local_size_z = Z) in;  ->  static const uint local_size[3] = {X, Y, Z};
+  3. floating-point literals without a suffix get an `f` (in GLSL `2.0` is a float; in C++ it would be a double
+     and silently widen the arithmetic).
+  4. the text is wrapped in `namespace glsl { namespace cs_<name> { ... } }` followed by glsl_cpu/harness.hpp.
+
+The radix sort (sort/hist.comp + sort/sort.comp x 8, Renderer.cpp:598-629) is NOT run: its result is by
+construction a stable ascending sort of the 64-bit keys, which gsr_sort_pairs does with std::stable_sort.
+
+Usage: python oracle/build_ref.py [--reference /root/reference] [--keep-generated DIR]
+"""
+import argparse
+import hashlib
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.path.join(HERE, "_ref")
+SHADERS = ["precomp_cov3d", "preprocess", "prefix_sum", "preprocess_sort", "tile_boundary", "render"]
+CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-w"]
+
+FLOAT_LIT = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![\w.])")
+BUFFER_BLOCK = re.compile(r"layout\s*\([^)]*\)\s*(?:readonly\s+|writeonly\s+)?buffer\s+\w+\s*\{\s*(\w+)\s+(\w+)\s*\[\s*\]\s*;\s*\}\s*;")
+UNIFORM_BLOCK = re.compile(r"layout\s*\([^)]*\)\s*uniform\s+\w+\s*\{(.*?)\}\s*;", re.S)
+IMAGE_DECL = re.compile(r"layout\s*\([^)]*\)\s*uniform\s+(?:writeonly\s+|readonly\s+)?image2D\s+(\w+)\s*;")
+LOCAL_SIZE = re.compile(r"layout\s*\(\s*local_size_x\s*=\s*([^,]+),\s*local_size_y\s*=\s*([^,]+),\s*local_size_z\s*=\s*([^)]+)\)\s*in\s*;")
+
+
+def glsl_to_cpp(text, shader_dir):
+    def include(m):
+        with open(os.path.join(shader_dir, m.group(1))) as f:
+            return f.read() + "\n"
+    text = re.sub(r'^\s*#include\s+"([^"]+)"\s*$', include, text, flags=re.M)
+    text = re.sub(r"^\s*#(version|extension)\b.*$", "", text, flags=re.M)
+    text = BUFFER_BLOCK.sub(lambda m: f"static buffer<{m.group(1)}> {m.group(2)};", text)
+    text = IMAGE_DECL.sub(lambda m: f"static image2D {m.group(1)};", text)
+
+    def members(m):
+        decls = [d.strip() for d in m.group(1).split(";") if d.strip()]
+        return "\n".join(f"static {d};" for d in decls)
+    text = UNIFORM_BLOCK.sub(members, text)
+    text = LOCAL_SIZE.sub(lambda m: f"static const uint local_size[3] = {{{m.group(1)}, {m.group(2)}, {m.group(3)}}};", text)
+    if re.search(r"\blayout\s*\(", text):
+        raise RuntimeError("unhandled layout declaration:\n" + "\n".join(l for l in text.splitlines() if "layout" in l))
+    out = []
+    for line in text.splitlines():  # rewrite 3, never inside a preprocessor line or a // comment
+        if line.lstrip().startswith("#"):
+            out.append(line)
+            continue
+        code, sep, comment = line.partition("//")
+        out.append(FLOAT_LIT.sub(r"\1f", code) + sep + comment)
+    return "\n".join(out)
+
+
+def sha256(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default=os.environ.get("GS_REFERENCE", "/root/reference"))
+    ap.add_argument("--keep-generated", default=None, help="also leave the generated C++ here (debugging; never commit)")
+    args = ap.parse_args()
+    shader_dir = os.path.join(args.reference, "src", "shaders")
+    if not os.path.isfile(os.path.join(shader_dir, "render.comp")):
+        print(f"build_ref: no reference shaders under {shader_dir}; keeping any prebuilt oracle/_ref", file=sys.stderr)
+        return 0 if os.path.exists(os.path.join(OUT_DIR, "libgs_ref.so")) else 1
+    os.makedirs(OUT_DIR, exist_ok=True)
+    compat = os.path.join(HERE, "glsl_cpu")
+    provenance = []
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_dir = args.keep_generated or tmp
+        os.makedirs(gen_dir, exist_ok=True)
+        objs = []
+        for name in SHADERS + ["common"]:
+            path = os.path.join(shader_dir, name + (".glsl" if name == "common" else ".comp"))
+            provenance.append(f"{os.path.relpath(path, args.reference)} sha256={sha256(path)}")
+        for name in SHADERS:
+            with open(os.path.join(shader_dir, name + ".comp")) as f:
+                body = glsl_to_cpp(f.read(), shader_dir)
+            src = os.path.join(gen_dir, f"cs_{name}.cpp")
+            with open(src, "w") as f:
+                f.write(f'#include "glsl_compat.hpp"\n#define CS_{name.upper()} 1\n'
+                        f"namespace glsl {{ namespace cs_{name} {{\n{body}\n#include \"harness.hpp\"\n}} }}\n")
+            obj = os.path.join(tmp, f"cs_{name}.o")
+            subprocess.check_call(["g++", *CXXFLAGS, "-I", compat, "-c", src, "-o", obj])
+            objs.append(obj)
+        prov = os.path.join(gen_dir, "provenance.cpp")
+        with open(prov, "w") as f:
+            lines = "\\n".join(provenance)
+            f.write(f'extern "C" const char* gsr_sources() {{ return "{lines}"; }}\n')
+        pobj = os.path.join(tmp, "provenance.o")
+        subprocess.check_call(["g++", *CXXFLAGS, "-c", prov, "-o", pobj])
+        sobj = os.path.join(tmp, "sort_pairs.o")
+        subprocess.check_call(["g++", *CXXFLAGS, "-c", os.path.join(compat, "sort_pairs.cpp"), "-o", sobj])
+        out = os.path.join(OUT_DIR, "libgs_ref.so")
+        subprocess.check_call(["g++", "-shared", "-fopenmp", *objs, pobj, sobj, "-o", out, "-lm"])
+    print(f"build_ref: {out}\n  " + "\n  ".join(provenance))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

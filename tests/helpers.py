@@ -43,3 +43,64 @@ def compare_stages(pkg, rend, u, ref):
     np.testing.assert_array_equal(rend.stage("sorted_tile"), (ref["sorted_keys"] >> np.uint64(32)).astype(np.uint32))
     np.testing.assert_array_equal(rend.stage("sorted_gid"), ref["sorted_payload"])
     np.testing.assert_array_equal(rend.stage("ranges", u), ref["boundaries"])
+
+
+# ---------------------------------------------------------------- image comparison across exp() implementations
+# render.comp:77 leaves exp() to the implementation (GLSL: 3 + 2|x| ULP) and :66/:87 may or may not be contracted
+# to FMAs.  Two conformant evaluations of the same lists therefore agree to a few ULP per pixel -- except where an
+# entry's alpha falls within rounding of the 1/255 cut (render.comp:78), its power within rounding of 0 (:68), or
+# the running transmittance within rounding of 1e-4 (:83): there the discrete decision can flip and the pixel moves
+# by up to alpha * T * rgb ~ 4e-3.  classify_pixel() re-traces one pixel in float64 and reports how close its list
+# comes to each threshold, so that a test can demand that EVERY pixel beyond ULP noise is such a flip, and count them.
+ULP_NOISE = 1e-5        # measured 3e-7 .. 2e-6; anything above this must be an explained threshold flip
+ALPHA_REL = 4e-6        # |alpha * 255 - 1| below this: alpha is within a few ULP of exp()/power of the cut
+T_REL = 2e-4            # |T' / 1e-4 - 1|: T is a product of up to thousands of factors, each a few ULP apart
+POWER_REL = 4e-6        # |power| relative to its terms
+
+
+def classify_pixel(attr, boundaries, payload, width, px, py):
+    tx = (width + 15) // 16
+    t = (py // 16) * tx + (px // 16)
+    ids = payload[boundaries[2 * t]:boundaries[2 * t + 1]]
+    a = attr[ids]
+    dx = a["uv"][:, 0].astype(np.float64) - px
+    dy = a["uv"][:, 1].astype(np.float64) - py
+    co = a["conic_opacity"].astype(np.float64)
+    t1, t2, t3 = co[:, 0] * dx * dx, co[:, 2] * dy * dy, co[:, 1] * dx * dy
+    power = -0.5 * (t1 + t2) - t3
+    mag = 0.5 * (np.abs(t1) + np.abs(t2)) + np.abs(t3) + 1e-300
+    alpha = np.minimum(0.99, co[:, 3] * np.exp(np.minimum(power, 0.0)))
+    near = dict(alpha=np.inf, power=np.inf, T=np.inf)
+    T = 1.0
+    for k in range(len(ids)):
+        near["power"] = min(near["power"], abs(power[k]) / mag[k] if mag[k] > 1e-30 else np.inf)
+        if power[k] > 0:
+            continue
+        near["alpha"] = min(near["alpha"], abs(alpha[k] * 255.0 - 1.0))
+        if alpha[k] < 1.0 / 255.0:
+            continue
+        test_T = T * (1.0 - alpha[k])
+        near["T"] = min(near["T"], abs(test_T / 1e-4 - 1.0))
+        if test_T < 1e-4:
+            break
+        T = test_T
+    return near
+
+
+def compare_images(img, ref_img, ref, width, label=""):
+    """img vs ref_img (both H x W x >=3), lists taken from `ref` (attr, boundaries, sorted_payload).
+    Asserts: every pixel differing by more than ULP_NOISE is an explained threshold flip, and there are at most
+    max(3, 1e-5 * P) of them.  Returns (max diff over unflipped pixels, list of flipped pixels)."""
+    d = np.abs(img[..., :3].astype(np.float64) - ref_img[..., :3]).max(axis=2)
+    ys, xs = np.nonzero(d > ULP_NOISE)
+    flips = []
+    for py, px in zip(ys.tolist(), xs.tolist()):
+        near = classify_pixel(ref["attr"], ref["boundaries"], ref["sorted_payload"], width, px, py)
+        explained = near["alpha"] < ALPHA_REL or near["T"] < T_REL or near["power"] < POWER_REL
+        flips.append((px, py, float(d[py, px]), near))
+        assert explained, f"{label} pixel ({px},{py}) differs by {d[py, px]:.3g} with no entry near a threshold: {near}"
+    assert len(flips) <= max(3, 1e-5 * d.size), f"{label}: {len(flips)} threshold-flip pixels"
+    assert d.max() <= 2.0 / 255.0 * max(1.0, float(np.abs(ref_img[..., :3]).max()))
+    rest = d.copy()
+    rest[ys, xs] = 0
+    return float(rest.max()), flips

@@ -1,10 +1,17 @@
-"""Committed golden fixture (tests/golden/scene_a1200.npz, made by tests/golden/make_golden.py)."""
+"""Committed golden fixture (tests/golden/scene_a1200.npz, made by tests/golden/make_golden.py).
+
+Every output in the file was computed by the reference's own shader text compiled for the CPU (oracle/_ref); the
+restated oracle and the HIP path must reproduce it: bit for bit in cov3D, the visible VertexAttribute records,
+tiles_overlap, the sorted payload and the tile boundaries; within 5e-6 in the image (render.comp's exp() is libm's
+there, the pipeline-defined polynomial here; the north-star bound is 1e-4).
+"""
 import os
 
 import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_a1200.npz")
+IMAGE_TOL = 5e-6  # a few ULP of exp() per term, accumulated over a pixel's list; measured 1.8e-6
 
 
 @pytest.fixture(scope="module")
@@ -12,16 +19,28 @@ def gold():
     return dict(np.load(GOLD))
 
 
+def test_fixture_was_made_from_the_reference_shader_text(gold):
+    src = str(gold["generator"])
+    for name in ("precomp_cov3d.comp", "preprocess.comp", "prefix_sum.comp", "preprocess_sort.comp",
+                 "tile_boundary.comp", "render.comp", "common.glsl"):
+        assert f"src/shaders/{name} sha256=" in src
+
+
 def test_oracle_reproduces_golden(oracle, gold):
     verts = oracle.activate_records(gold["records"])
     u = oracle.camera_uniforms(gold["camera"], int(gold["uniforms"]["width"][0]), int(gold["uniforms"]["height"][0]))
     assert u.tobytes() == gold["uniforms"].tobytes()
     st = oracle.stages(verts, u)
+    assert st["cov3d"].tobytes() == gold["cov3d"].tobytes()
     np.testing.assert_array_equal(st["tiles"], gold["tiles"])
+    vis = st["tiles"] > 0
+    for f in ("conic_opacity", "color_radii", "aabb", "uv", "depth"):
+        assert np.ascontiguousarray(st["attr"][f][vis]).tobytes() == \
+            np.ascontiguousarray(gold["visible_attr"][f]).tobytes(), f
     np.testing.assert_array_equal((st["sorted_keys"] >> np.uint64(32)).astype(np.uint32), gold["sorted_tile"])
     np.testing.assert_array_equal(st["sorted_payload"], gold["sorted_payload"])
     np.testing.assert_array_equal(st["boundaries"], gold["boundaries"])
-    np.testing.assert_array_equal(st["image"][..., :3], gold["image"])
+    assert np.abs(st["image"][..., :3] - gold["image"]).max() <= IMAGE_TOL
 
 
 @pytest.mark.gpu
@@ -33,7 +52,13 @@ def test_hip_reproduces_golden(pkg, gpu, gold):
     assert u.tobytes() == gold["uniforms"].tobytes()
     img, _ = rend.render_host(u)
     np.testing.assert_array_equal(rend.stage("tiles"), gold["tiles"])
-    np.testing.assert_array_equal(rend.stage("sorted_tile"), gold["sorted_tile"])
+    vis = gold["tiles"] > 0
+    va = gold["visible_attr"]
+    np.testing.assert_array_equal(rend.stage("conic_opacity").reshape(-1, 4)[vis].view(np.uint32),
+                                  np.ascontiguousarray(va["conic_opacity"]).view(np.uint32))
+    np.testing.assert_array_equal(rend.stage("depth")[vis].view(np.uint32), va["depth"].view(np.uint32))
+    np.testing.assert_array_equal(rend.stage("uv_rg").reshape(-1, 4)[vis][:, :2].view(np.uint32),
+                                  np.ascontiguousarray(va["uv"]).view(np.uint32))
     np.testing.assert_array_equal(rend.stage("sorted_gid"), gold["sorted_payload"])
     np.testing.assert_array_equal(rend.stage("ranges", u), gold["boundaries"])
-    assert np.abs(img[..., :3] - gold["image"]).max() <= 1e-4
+    assert np.abs(img[..., :3] - gold["image"]).max() <= IMAGE_TOL

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import compare_stages, oracle_frame
+from helpers import compare_images, compare_stages, oracle_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +37,34 @@ def test_config_a_stages_and_pixels(pkg, oracle, gpu):
     assert np.abs(img - ref["image"]).max() <= PIXEL_TOL
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
     np.testing.assert_array_equal(bgra, oracle.pack_bgra8(ref["image"]))
+
+
+def test_hip_against_the_reference_shader_text(pkg, oracle, gpu):
+    """HIP path vs oracle/_ref (the reference's .comp files compiled for the CPU) with no oracle in between:
+    config A and a rotated camera.  Integer stages and preprocess floats bit for bit, the image to ULP noise apart
+    from counted alpha-threshold pixels (different exp(): helpers.compare_images)."""
+    import __graft_entry__ as entry
+    refl = entry.load_ref()
+    if not refl.available():
+        pytest.skip("oracle/_ref did not travel to this box")
+    q = np.array([0.9, 0.1, -0.3, 0.05], np.float32)
+    q /= np.linalg.norm(q)
+    for n, w, h, cam in [(10000, 256, 256, None), (8000, 640, 360, dict(position=(0.3, -0.2, 0.5), rotation=tuple(q)))]:
+        rec = pkg.synth.synth_records(n, seed=n, kind="A")
+        verts = oracle.activate_records(rec)
+        ocam = oracle.default_camera(**cam) if cam else oracle.default_camera()
+        u_ref = oracle.camera_uniforms(ocam, w, h)
+        sr = refl.stages(verts, u_ref)
+        scene = pkg.Scene.from_records(rec, device=0)
+        rend = pkg.Renderer(scene)
+        u = pkg.camera_uniforms(pkg.make_camera(**cam) if cam else pkg.make_camera(), w, h)
+        assert u.tobytes() == u_ref.tobytes()
+        img, _ = rend.render_host(u)
+        np.testing.assert_array_equal(scene.download_cov3d().view(np.uint32), sr["cov3d"].view(np.uint32))
+        compare_stages(pkg, rend, u, sr)
+        rest, flips = compare_images(img, sr["image"], sr, w, label=f"HIP vs reference text {w}x{h}")
+        print(f"HIP vs reference shader text, {n} @ {w}x{h}: off-threshold max {rest:.3g}, flips "
+              f"{[(x, y, round(d, 6)) for x, y, d, _ in flips]}")
 
 
 @pytest.mark.parametrize("w,h", [(200, 120), (33, 17), (16, 16), (1, 1), (641, 359), (4100, 2200), (7680, 4320)])
