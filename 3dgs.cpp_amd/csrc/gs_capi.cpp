@@ -112,7 +112,9 @@ struct gs_scene {
 
     void finish_load() {  // GSScene::precomputeCov3D, GSScene.cpp:157-184
         cov3d.alloc(6 * n);
-        gs::launch_cov3d(blob, cov3d.p, static_cast<uint32_t>(n), nullptr);
+        if (reinterpret_cast<uintptr_t>(blob) % 64 != 0)
+            throw Error(GS_ERR_INVALID, "the scene blob must be 64-byte aligned (SH blocks are read as 16-byte vectors)");
+        gs::launch_cov3d(blob, cov3d.p, static_cast<uint32_t>(n), static_cast<uint32_t>(gs::blob_stride(n)), nullptr);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(nullptr));
     }
@@ -143,15 +145,16 @@ void upload_vertices(gs_scene* s, const float* vertices, uint64_t n) {
     // AoS GSScene::Vertex[n] -> blob: 11 SoA planes (pos3, scale3, rot4, opacity) + AoS SH block (48 per Gaussian)
     if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
     s->n = n;
-    std::vector<float> planes(static_cast<size_t>(gs::P_COUNT) * n);
+    const size_t st = gs::blob_stride(n);
+    std::vector<float> planes(gs::blob_floats(n));
     parallel_for(n, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t i = lo; i < hi; ++i) {
             const float* v = vertices + i * gs::host::kVertexFloats;
-            for (int k = 0; k < 3; ++k) planes[(gs::P_POS + k) * n + i] = v[k];
-            for (int k = 0; k < 3; ++k) planes[(gs::P_SCALE + k) * n + i] = v[4 + k];
-            for (int k = 0; k < 4; ++k) planes[(gs::P_ROT + k) * n + i] = v[8 + k];
-            planes[static_cast<size_t>(gs::P_OPACITY) * n + i] = v[7];
-            std::memcpy(&planes[static_cast<size_t>(gs::P_SH) * n + i * 48], v + 12, 48 * sizeof(float));
+            for (int k = 0; k < 3; ++k) planes[(gs::P_POS + k) * st + i] = v[k];
+            for (int k = 0; k < 3; ++k) planes[(gs::P_SCALE + k) * st + i] = v[4 + k];
+            for (int k = 0; k < 4; ++k) planes[(gs::P_ROT + k) * st + i] = v[8 + k];
+            planes[static_cast<size_t>(gs::P_OPACITY) * st + i] = v[7];
+            std::memcpy(&planes[static_cast<size_t>(gs::P_SH) * st + i * 48], v + 12, 48 * sizeof(float));
         }
     });
     s->owned_blob.alloc(planes.size());
@@ -363,8 +366,9 @@ void load_ply_streamed(gs_scene* s, const std::string& path) {
     const uint64_t n = L.n;
     if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
     s->n = n;
-    s->owned_blob.alloc(static_cast<size_t>(gs::P_COUNT) * n);
+    s->owned_blob.alloc(gs::blob_floats(n));
     s->blob = s->owned_blob.p;
+    const size_t st = gs::blob_stride(n);
     if (n) {
         constexpr uint64_t kChunk = 1ull << 18;
         const uint64_t chunk = std::min(kChunk, n);
@@ -403,9 +407,9 @@ void load_ply_streamed(gs_scene* s, const std::string& path) {
                     }
                 });
                 for (int p = 0; p < gs::P_SH; ++p)
-                    HIP_CHECK(hipMemcpyAsync(s->blob + static_cast<size_t>(p) * n + c0, buf + static_cast<size_t>(p) * chunk,
+                    HIP_CHECK(hipMemcpyAsync(s->blob + static_cast<size_t>(p) * st + c0, buf + static_cast<size_t>(p) * chunk,
                                              cnt * sizeof(float), hipMemcpyHostToDevice, up));
-                HIP_CHECK(hipMemcpyAsync(s->blob + static_cast<size_t>(gs::P_SH) * n + c0 * 48,
+                HIP_CHECK(hipMemcpyAsync(s->blob + static_cast<size_t>(gs::P_SH) * st + c0 * 48,
                                          buf + static_cast<size_t>(gs::P_SH) * chunk, cnt * 48 * sizeof(float),
                                          hipMemcpyHostToDevice, up));
                 HIP_CHECK(hipEventRecord(freed[c & 1], up));
@@ -471,6 +475,11 @@ struct FrameBuffers {
         for (int k = 0; k < 2; ++k) {
             ikeys[k].alloc(cap);
             ivals[k].alloc(cap);
+            // a frame whose candidates overflow the capacity leaves a gap of unwritten entries that the bin kernels
+            // still gather through before the frame is re-run: the gap must hold valid Gaussian ids (0), never
+            // whatever hipMalloc handed back
+            HIP_CHECK(hipMemset(ikeys[k].p, 0, static_cast<size_t>(cap) * sizeof(uint32_t)));
+            HIP_CHECK(hipMemset(ivals[k].p, 0, static_cast<size_t>(cap) * sizeof(uint32_t)));
         }
         sorted.alloc(static_cast<size_t>(cap) + 4);  // + 4: a 16-byte list store that starts inside the capacity may end past it
     }
@@ -519,7 +528,8 @@ struct gs_renderer {
     uint32_t frames_since_fallback = 0;
     bool use_bin_local() const { return sort_mode == 2 || (sort_mode == 0 && bin_local_ok); }
     bool have_frame = false;
-    uint32_t retries = 0;
+    uint32_t retries = 0;        // lifetime count of re-run frames (statistics only)
+    uint32_t redo_chain = 0;     // consecutive re-runs since a frame last retired cleanly: the runaway guard
     double total_ms[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t total_frames = 0;
     // completion-to-completion intervals of consecutive frames (the frame time a consumer sees with frames in flight)
@@ -556,7 +566,9 @@ struct gs_renderer {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(gs::Counters), hipHostMallocDefault));
             *sl.h_counters = gs::Counters{};
         }
-        const uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(scene->n));
+        uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(scene->n));
+        // test knob: start small so that the overflow / grow / re-run machinery is exercised by small scenes
+        if (const char* e = std::getenv("GS_INITIAL_CAPACITY")) want = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
         capacity = static_cast<uint32_t>(std::min<uint64_t>(want, kMaxInstances));
         sets[0].init(scene->n, capacity);
     }
@@ -642,7 +654,7 @@ struct gs_renderer {
         num_tiles = nt;
         ensure_tile_order(tx, ty);
 
-        gs::SceneView sv{scene->blob, scene->cov3d.p, n};
+        gs::SceneView sv{scene->blob, scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n))};
         gs::AttrView av{tiles.p, depth.p, radius.p, aabb.p, conic_op.p, uv_rg.p, bch.p};
         gs::Counters* cnt = counters.p;
 
@@ -804,7 +816,9 @@ struct gs_renderer {
                 bin_local_ok = false;
                 frames_since_fallback = 0;
             }
-            if (retries > 64) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
+            // runaway guard: one frame may need a path fall-back and a few grow steps (each grow is sized from the counts
+            // the overflowing frame reported, so it converges at once unless the chunk table and the lists take turns)
+            if (++redo_chain > 8) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
             if (grow) {
                 need = need + need / 2 + 4096;  // 1.5x head-room: a moving camera should not re-grow every few frames
                 if (need > kMaxInstances) throw Error(GS_ERR_OVERFLOW, "more than 2^30 tile instances");
@@ -814,6 +828,7 @@ struct gs_renderer {
             for (const Redo& f : redo) enqueue(f.u, f.rgba, f.bgra);
             return;
         }
+        redo_chain = 0;
         if (sort_mode == 0 && !bin_local_ok) {  // back to the bin-local path once the bins have fitted for a while
             if (sl.h_counters->max_bin <= static_cast<uint32_t>(gs::kBinSortMax) * 7 / 8) {
                 if (++frames_since_fallback >= 32) bin_local_ok = true;
@@ -948,7 +963,7 @@ int gs_scene_from_vertices(const float* vertices, uint64_t n, int device, gs_sce
     });
 }
 
-uint64_t gs_scene_blob_floats(uint64_t n) { return static_cast<uint64_t>(gs::P_COUNT) * n; }
+uint64_t gs_scene_blob_floats(uint64_t n) { return gs::blob_floats(n); }
 
 int gs_scene_from_device_blob(float* d_blob, uint64_t n, int device, gs_scene** out) {
     return guarded([&] {
@@ -979,16 +994,17 @@ int gs_scene_download_vertices(const gs_scene* s, float* vertices) {
         if (!s || (!vertices && s->n)) throw Error(GS_ERR_INVALID, "null argument");
         HIP_CHECK(hipSetDevice(s->device));
         const uint64_t n = s->n;
-        std::vector<float> planes(static_cast<size_t>(gs::P_COUNT) * n);
+        const size_t st = gs::blob_stride(n);
+        std::vector<float> planes(gs::blob_floats(n));
         if (n) HIP_CHECK(hipMemcpy(planes.data(), s->blob, planes.size() * sizeof(float), hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < n; ++i) {
             float* v = vertices + i * gs::host::kVertexFloats;
-            for (int k = 0; k < 3; ++k) v[k] = planes[(gs::P_POS + k) * n + i];
+            for (int k = 0; k < 3; ++k) v[k] = planes[(gs::P_POS + k) * st + i];
             v[3] = 1.0f;
-            for (int k = 0; k < 3; ++k) v[4 + k] = planes[(gs::P_SCALE + k) * n + i];
-            v[7] = planes[static_cast<size_t>(gs::P_OPACITY) * n + i];
-            for (int k = 0; k < 4; ++k) v[8 + k] = planes[(gs::P_ROT + k) * n + i];
-            for (int k = 0; k < 48; ++k) v[12 + k] = planes[static_cast<size_t>(gs::P_SH) * n + i * 48 + k];
+            for (int k = 0; k < 3; ++k) v[4 + k] = planes[(gs::P_SCALE + k) * st + i];
+            v[7] = planes[static_cast<size_t>(gs::P_OPACITY) * st + i];
+            for (int k = 0; k < 4; ++k) v[8 + k] = planes[(gs::P_ROT + k) * st + i];
+            for (int k = 0; k < 48; ++k) v[12 + k] = planes[static_cast<size_t>(gs::P_SH) * st + i * 48 + k];
         }
     });
 }

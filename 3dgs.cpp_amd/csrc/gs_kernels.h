@@ -13,14 +13,19 @@ constexpr int kSortTileKeys = 2048;   // keys per radix tile (256 threads x 8)
 constexpr int kSortMaxBlocks = 1024;  // fixed sort grid (data-dependent sizes stay on the device)
 constexpr int kScanBlocks = 512;      // fixed scan grid
 
-// Packed scene blob (59 floats per Gaussian): planes 0..10 are SoA -- plane p of Gaussian i is blob[p*n + i] --
-// followed by the SH block as AoS: the 48 SH floats of Gaussian i are blob[11*n + 48*i .. +48).
+// Packed scene blob (59 floats per Gaussian + padding): planes 0..10 are SoA with a plane stride of
+// blob_stride(n) = n rounded up to 16 floats -- plane p of Gaussian i is blob[p*stride + i] -- followed by the SH
+// block as AoS: the 48 SH floats of Gaussian i are blob[11*stride + 48*i .. +48).  With the blob itself 64-byte
+// aligned, every plane and every Gaussian's 192-byte SH block start on a 64-byte line for any n.
 enum ScenePlane { P_POS = 0, P_SCALE = 3, P_ROT = 6, P_OPACITY = 10, P_SH = 11, P_COUNT = 59 };
+constexpr uint64_t blob_stride(uint64_t n) { return (n + 15) & ~uint64_t(15); }
+constexpr uint64_t blob_floats(uint64_t n) { return P_SH * blob_stride(n) + 48 * n; }
 
 struct SceneView {
-    const float* blob;   // 59 planes
-    const float* cov3d;  // 6 planes
+    const float* blob;   // 11 planes of `stride` floats, then n x 48 SH floats
+    const float* cov3d;  // 6 planes of n floats
     uint32_t n;
+    uint32_t stride;     // blob_stride(n)
 };
 
 // Per-frame buffers indexed by Gaussian id.
@@ -45,7 +50,7 @@ struct Counters {
 };
 constexpr int kBinSortMax = 16384;  // candidates per bin that k_bin_sort can order in LDS (128 KiB of (key, id))
 
-void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s);
+void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s);
 // counters (nullable): the kernel clears counters->overflow, so that a frame needs no memset node.
 // nbins (nullable): [N] bins of (1 << bin_shift)^2 tiles touched by each Gaussian's tile box, 0 when culled.
 void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,

@@ -98,10 +98,10 @@ __device__ __forceinline__ M3 rotation_from_quaternion(float qw, float qx, float
 }
 
 __global__ __launch_bounds__(BLOCK) void k_cov3d(const float* __restrict__ blob, float* __restrict__ cov3d,
-                                                 uint32_t n) {
+                                                 uint32_t n, uint32_t stride) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const size_t N = n;
+    const size_t N = stride, NC = n;
     const float scale_factor = 1.0f;  // GSScene.cpp:176
     M3 S = {};
     S.c[0][0] = blob[(P_SCALE + 0) * N + i] * scale_factor;
@@ -111,17 +111,17 @@ __global__ __launch_bounds__(BLOCK) void k_cov3d(const float* __restrict__ blob,
                                     blob[(P_ROT + 2) * N + i], blob[(P_ROT + 3) * N + i]);
     M3 M = m3_mul(S, R);
     M3 C = m3_mul(m3_transpose(M), M);
-    cov3d[0 * N + i] = C.c[0][0];
-    cov3d[1 * N + i] = C.c[0][1];
-    cov3d[2 * N + i] = C.c[0][2];
-    cov3d[3 * N + i] = C.c[1][1];
-    cov3d[4 * N + i] = C.c[1][2];
-    cov3d[5 * N + i] = C.c[2][2];
+    cov3d[0 * NC + i] = C.c[0][0];
+    cov3d[1 * NC + i] = C.c[0][1];
+    cov3d[2 * NC + i] = C.c[0][2];
+    cov3d[3 * NC + i] = C.c[1][1];
+    cov3d[4 * NC + i] = C.c[1][2];
+    cov3d[5 * NC + i] = C.c[2][2];
 }
 
-void launch_cov3d(const float* blob, float* cov3d, uint32_t n, hipStream_t s) {
+void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_cov3d, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob, cov3d, n);
+    hipLaunchKernelGGL(k_cov3d, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob, cov3d, n, stride);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         pu.counters->overflow = 0;
         pu.counters->max_bin = 0;
     }
-    const size_t N = sv.n;
+    const size_t N = sv.stride, NC = sv.n;
     const float* __restrict__ blob = sv.blob;
 
     const int tile_w = (int)((u.width + kTile - 1) / kTile);
@@ -212,8 +212,8 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
 #pragma unroll
             for (int r = 0; r < 3; ++r) W.c[c][r] = u.view_mat[r * 4 + c];
         const float* __restrict__ cv = sv.cov3d;
-        const float s0 = cv[0 * N + i], s1 = cv[1 * N + i], s2 = cv[2 * N + i];
-        const float s3 = cv[3 * N + i], s4 = cv[4 * N + i], s5 = cv[5 * N + i];
+        const float s0 = cv[0 * NC + i], s1 = cv[1 * NC + i], s2 = cv[2 * NC + i];
+        const float s3 = cv[3 * NC + i], s4 = cv[4 * NC + i], s5 = cv[5 * NC + i];
         M3 Sigma;
         Sigma.c[0][0] = s0;
         Sigma.c[0][1] = s1;
@@ -1306,7 +1306,8 @@ void launch_bin_fill(const BinLaunch& b, hipStream_t s) {
 // Exactness of the culling: an entry contributes to a pixel only if alpha = min(0.99, o*exp(power))
 // >= 1/255, i.e. power >= -tau with tau = ln(255*o), and -power = q(d) = 0.5 d^T C d (C = conic) is
 // a convex quadratic of d = uv - pixel.  If the minimum of q over the quadrant's pixel rectangle exceeds
-// tau (with 0.1 % + 1e-3 slack against ~1e-6 relative rounding in power/exp/log), every pixel of the
+// tau (with 0.1 % + 1e-3 slack against the rounding of exp/log, plus 8 ULP of the quadratic's largest TERMS over the
+// quadrant against the cancellation error of `power` for thin diagonal splats), every pixel of the
 // quadrant executes `continue` in the shader, so skipping the entry for that wave changes nothing.
 // The same bound gives a per-entry lower limit on power below which exp() need not be evaluated.
 // ---------------------------------------------------------------------------------------
@@ -1434,7 +1435,15 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
             if (keep) {
                 const float mq = min_q_rect(cur.co.x, cur.co.y, cur.co.z, cur.uv.x, cur.uv.y, rx0, rx0 + 7.0f,
                                             ry0, ry0 + 7.0f);
-                keep = !(mq > lim);  // NaN -> keep
+                // The rounding error of the shader's `power` (and of mq) is relative to the TERMS c00 dx^2, c11 dy^2,
+                // c01 dx dy, not to their sum: a thin diagonal splat far from its centre has terms ~1e5 cancelling to
+                // q ~ 5.  The slack therefore grows with the terms at the quadrant's corner farthest from the centre
+                // (8 roundings of 2^-24 each, generously).
+                const float ax = fmaxf(fabsf(cur.uv.x - rx0), fabsf(cur.uv.x - (rx0 + 7.0f)));
+                const float ay = fmaxf(fabsf(cur.uv.y - ry0), fabsf(cur.uv.y - (ry0 + 7.0f)));
+                const float mag = __builtin_fmaf(0.5f * fabsf(cur.co.x) * ax, ax,
+                                                 __builtin_fmaf(0.5f * fabsf(cur.co.z) * ay, ay, fabsf(cur.co.y) * ax * ay));
+                keep = !(mq > __builtin_fmaf(mag, 4.8e-7f, lim));  // NaN -> keep
             }
             uint64_t bm = __ballot(keep);
             STAT_ADD(0, 1);

@@ -38,7 +38,7 @@ public:
     HeadlessWindow(std::string name, int width, int height);
     [[nodiscard]] std::pair<uint32_t, uint32_t> getFramebufferSize() const override { return {width, height}; }
     std::array<double, 2> getCursorTranslation() override;
-    std::array<bool, 3> getMouseButton() override { return {captureRequested, false, false}; }
+    std::array<bool, 3> getMouseButton() override { return {buttonDown, false, false}; }
     std::array<bool, 7> getKeys() override { return keys; }
     bool tick() override;
     void logTranslation(float x, float y) override;
@@ -53,7 +53,7 @@ private:
     long long frameBudget = 1;
     long long ticks = 0;
     double accumulatedX = 0, accumulatedY = 0;
-    bool captureRequested = false;
+    bool buttonDown = false;
     std::string dumpDir;
     struct ScriptedInput {
         double dx, dy;

@@ -46,10 +46,14 @@ HeadlessWindow::HeadlessWindow(std::string name_, int w, int h)
 bool HeadlessWindow::tick() {
     if (frameBudget > 0 && ticks >= frameBudget) return false;
     keys = {};
+    buttonDown = false;  // polled state, like glfwGetMouseButton: held only while this tick's input says so
     if (static_cast<size_t>(ticks) < script.size()) {  // this tick's polled input
         const ScriptedInput& in = script[static_cast<size_t>(ticks)];
         keys = in.keys;
-        if (in.dx != 0.0 || in.dy != 0.0) logTranslation(static_cast<float>(in.dx), static_cast<float>(in.dy));
+        if (in.dx != 0.0 || in.dy != 0.0) {
+            logTranslation(static_cast<float>(in.dx), static_cast<float>(in.dy));
+            buttonDown = true;  // a scripted drag: button 0 is down on the ticks that carry a cursor delta
+        }
     }
     ++ticks;
     return true;
@@ -61,8 +65,7 @@ std::array<double, 2> HeadlessWindow::getCursorTranslation() {
 }
 void HeadlessWindow::logTranslation(float x, float y) {
     accumulatedX += x;
-    accumulatedY += y;
-    captureRequested = true;  // a host that pans wants the camera to follow (mouse button 0 in the reference)
+    accumulatedY += y;  // windowing/MetalWindow.cpp:41-45: deltas only, no button
 }
 void HeadlessWindow::present(const uint8_t* bgra, uint32_t w, uint32_t h) {
     if (!dumpDir.empty()) {
@@ -135,11 +138,12 @@ void Renderer::initialize() {  // Renderer.cpp:19-31 without Vulkan / swapchain 
 void Renderer::handleInput() {  // Renderer.cpp:33-83 (GUI capture checks drop out: there is no GUI)
     const auto translation = window->getCursorTranslation();
     const auto keys = window->getKeys();
-    if (window->getMouseButton()[0]) {
+    // There is no ImGui here: wantCaptureMouse / wantCaptureKeyboard are false; guiManager.mouseCapture is mouseCaptured.
+    if ((!configuration.enableGui || !mouseCaptured) && window->getMouseButton()[0]) {
         window->mouseCapture(true);
         mouseCaptured = true;
     }
-    if (mouseCaptured && (translation[0] != 0.0 || translation[1] != 0.0)) {
+    if ((!configuration.enableGui || mouseCaptured) && (translation[0] != 0.0 || translation[1] != 0.0)) {
         camera.rotation = gs::rotate(camera.rotation, static_cast<float>(translation[0]) * 0.005f, gs::vec3{0.0f, -1.0f, 0.0f});
         camera.rotation = gs::rotate(camera.rotation, static_cast<float>(translation[1]) * 0.005f, gs::vec3{-1.0f, 0.0f, 0.0f});
     }

@@ -90,7 +90,7 @@ def main():
     n, w, h = args.gaussians, args.width, args.height
 
     # ---- scene: built on rank 0, broadcast as one packed SoA blob (59 floats / Gaussian) ----
-    blob = torch.empty(59 * n, dtype=torch.float32, device=dev)
+    blob = torch.empty(pkg.dist.blob_floats(n), dtype=torch.float32, device=dev)
     if rank == 0:
         rec = pkg.synth.synth_records(n, seed=0, kind="S")
         scene0 = pkg.Scene.from_records(rec, device=local_rank)  # GSScene::load path (activations on host)

@@ -119,8 +119,9 @@ int gs_scene_from_records(const float* records, uint64_t n, int device, gs_scene
 int gs_scene_from_vertices(const float* vertices, uint64_t n, int device, gs_scene** out);
 
 /* Adopt a packed SoA blob already resident in HBM (gs_scene_blob_floats(n) floats:
- * 11 SoA planes pos[3][n] scale[3][n] rot[4][n] opacity[n], then the SH block as AoS sh[n][48]);
- * the caller keeps it alive.
+ * 11 SoA planes pos[3] scale[3] rot[4] opacity[1], each padded to st = n rounded up to 16 floats, then the SH
+ * block as AoS sh[n][48]; d_blob must be 64-byte aligned, which makes every plane and every Gaussian's 192-byte
+ * SH block start on a 64-byte line); the caller keeps it alive.
  * This is the multi-GPU path: rank 0 builds the blob, RCCL broadcasts it, every rank
  * adopts its copy.  No reference counterpart (the reference is single-GPU). */
 int gs_scene_from_device_blob(float* d_blob, uint64_t n, int device, gs_scene** out);

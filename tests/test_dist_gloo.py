@@ -20,7 +20,7 @@ def _worker(rank, world, port, out_dir):
     pkg, oracle = entry.load_package(), entry.load_oracle()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    blob = torch.zeros(pkg.dist.BLOB_PLANES * N, dtype=torch.float32)
+    blob = torch.zeros(pkg.dist.blob_floats(N), dtype=torch.float32)
     if rank == 0:
         rec = pkg.synth.synth_records(N, seed=21, kind="A")
         blob.copy_(torch.from_numpy(pkg.dist.pack_blob(pkg.activate_records(rec))))

@@ -407,3 +407,75 @@ def test_bin_local_sort_at_its_capacity(pkg, oracle, gpu, monkeypatch):
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
     rend.close()
     scene.close()
+
+
+def test_many_path_fallbacks_do_not_exhaust_a_lifetime_budget(pkg, oracle, gpu, monkeypatch):
+    """A fly-through that enters and leaves a dense bin: every entry re-runs the frame on the global depth order
+    (one redo each), every exit returns to the bin-local path after 32 fitting frames.  More than 70 such round
+    trips must neither raise GS_ERR_OVERFLOW (the guard counts CONSECUTIVE re-runs of a frame) nor change a pixel."""
+    monkeypatch.setenv("GS_SORT_PATH", "0")  # automatic path choice is what is under test
+    rec = pkg.synth.synth_records(30000, seed=21, kind="A")
+    rec[:, 0] = rec[:, 0] * 0.01 + 0.2     # all of them inside one bin: 30 000 candidates > kBinSortMax
+    rec[:, 1] = rec[:, 1] * 0.01 - 0.1
+    w, h = 512, 288
+    verts = oracle.activate_records(rec)
+    scene = pkg.Scene.from_records(rec, device=0)
+    rend = pkg.Renderer(scene)
+    dense = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    away = pkg.camera_uniforms(pkg.make_camera(rotation=pkg.dist.pose_quaternion(18, 10.0)), w, h)  # looking backwards
+    dev = _HipBuffers()
+    target = dev.alloc(w * h * 16)
+    for trip in range(72):
+        rend.render(dense, target, 0)
+        for _ in range(33):
+            rend.render(away, target, 0)
+    rend.render(dense, target, 0)
+    rend.synchronize()
+    st = rend.stats()
+    assert st.retries >= 72, st.retries
+    assert st.sort_path == 1 and st.max_bin_entries > 16384
+    ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), w, h))
+    np.testing.assert_array_equal(dev.download(target, (h, w, 4), np.float32), ref["image"])
+    np.testing.assert_array_equal(rend.stage("sorted_gid"), ref["sorted_payload"])
+    dev.close()
+
+
+def test_candidate_overflow_on_fresh_buffers(pkg, oracle, gpu, monkeypatch):
+    """Level-1 candidates AND instances beyond a tiny initial capacity, first frame of a renderer (buffers straight
+    from hipMalloc): the bin kernels run over the unwritten gap before the frame is re-run, which must stay in
+    bounds; the re-run frames are exact.  Several grow steps in a row stay inside the consecutive-redo guard."""
+    monkeypatch.setenv("GS_INITIAL_CAPACITY", "1024")
+    rec = pkg.synth.synth_records(4000, seed=22, kind="A")
+    rec[:200, 55:58] = 1.0   # 200 screen-filling splats: they touch every bin
+    w, h = 1280, 720
+    verts = oracle.activate_records(rec)
+    for flights in (1, 3):
+        scene = pkg.Scene.from_records(rec, device=0)
+        rend = pkg.Renderer(scene)
+        rend.set_frames_in_flight(flights)
+        u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+        img, _ = rend.render_host(u)
+        st = rend.stats()
+        ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), w, h))
+        assert st.retries >= 1 and st.num_instances == len(ref["keys"]) and st.num_bin_entries > 1024
+        assert st.instance_capacity >= st.num_instances
+        compare_stages(pkg, rend, u, ref)
+        np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+        rend.close()
+        scene.close()
+
+
+def test_needle_gaussians(pkg, oracle, gpu):
+    """Thin, long, randomly oriented splats (sigma ratio up to e^7): far from the centre the terms of `power` are
+    ~1e5 and cancel to a few units, so the per-quadrant culling bound must carry a term-scaled slack.  Bit-exact
+    image, and the lists as usual."""
+    for seed, n, w, h in [(31, 6000, 640, 360), (32, 20000, 1920, 1080)]:
+        rec = pkg.synth.synth_records(n, seed=seed, kind="A")
+        rng = np.random.default_rng(seed)
+        rec[:, 55] = rng.uniform(-1.5, 0.0, n)          # long axis: sigma 0.2 .. 1 world units
+        rec[:, 56:58] = rng.uniform(-9.0, -6.0, (n, 2))  # thin axes: sub-pixel
+        rec[:, 58:62] = rng.normal(size=(n, 4))          # random orientation
+        rec[:, 54] = rng.uniform(0.0, 4.0, n)            # fairly opaque, so that tau is large
+        scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
+        compare_stages(pkg, rend, u, ref)
+        np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
