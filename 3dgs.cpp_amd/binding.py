@@ -21,6 +21,17 @@ VERTEX_FLOATS = 60
 RECORD_FLOATS = 62
 BLOB_PLANES = 59
 
+
+def library_source_hash():
+    """sha256 over the sources libgs3d_hip.so is built from: ties a committed rocprofv3 counter file to the kernels
+    it was collected on (bench.py refuses counters of other sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("gs_kernels.hip", "gs_kernels.h", "gs_capi.cpp", "gs_host_math.h", "Makefile"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
 STAGES = dict(tiles=(0, np.uint32), depth=(1, np.float32), radius=(2, np.float32), aabb=(3, np.uint16),
               conic_opacity=(4, np.float32), uv_rg=(5, np.float32), b=(6, np.float32),
               depth_order=(7, np.uint32), sorted_tile=(11, np.uint32), sorted_gid=(12, np.uint32),
