@@ -40,10 +40,13 @@ STAGES = dict(tiles=(0, np.uint32), depth=(1, np.float32), radius=(2, np.float32
 # every symbol include/gs3d_hip.h declares
 SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_records", "gs_scene_load_ply", "gs_scene_from_records",
            "gs_scene_from_vertices", "gs_scene_from_device_blob", "gs_scene_blob_floats", "gs_scene_blob",
-           "gs_scene_num_vertices", "gs_scene_download_vertices", "gs_scene_download_cov3d",
+           "gs_scene_num_vertices", "gs_scene_quantize_sh", "gs_scene_sh_bits", "gs_scene_download_vertex_range",
+           "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
-           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_get_timing_totals",
-           "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_renderer_stream"]
+           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_get_timing_totals",
+           "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_renderer_stream",
+           "gs_dist_unique_id", "gs_dist_create", "gs_dist_rank", "gs_dist_world", "gs_dist_pose_count",
+           "gs_dist_broadcast_scene", "gs_dist_destroy"]
 
 
 class FrameStats(C.Structure):
@@ -185,6 +188,19 @@ class Scene:
         _check(lib().gs_scene_download_vertices(self._h, _p(out)))
         return out
 
+    def quantize_sh(self):
+        """Round the SH coefficients to binary16 storage (opt-in; gs_scene_quantize_sh)."""
+        _check(lib().gs_scene_quantize_sh(self._h))
+
+    @property
+    def sh_bits(self):
+        return lib().gs_scene_sh_bits(self._h)
+
+    def download_vertex_range(self, first, count):
+        out = np.zeros((count, VERTEX_FLOATS), np.float32)
+        _check(lib().gs_scene_download_vertex_range(self._h, C.c_uint64(first), C.c_uint64(count), _p(out)))
+        return out
+
     def download_cov3d(self):
         out = np.zeros((self.num_vertices, 6), np.float32)
         _check(lib().gs_scene_download_cov3d(self._h, _p(out)))
@@ -231,6 +247,10 @@ class Renderer:
     def set_frames_in_flight(self, frames):
         _check(lib().gs_set_frames_in_flight(self._h, C.c_int(int(frames))))
 
+    def set_exp_mode(self, mode):
+        """0 pipeline-defined exp (exact), 1 hardware v_exp_f32 (gs_set_exp_mode)."""
+        _check(lib().gs_set_exp_mode(self._h, C.c_int(int(mode))))
+
     def set_sort_path(self, mode):
         """0 automatic, 1 global depth order, 2 bin-local (gs_set_sort_path)."""
         _check(lib().gs_set_sort_path(self._h, C.c_int(int(mode))))
@@ -275,6 +295,55 @@ class Renderer:
     def close(self):
         if self._h:
             lib().gs_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dist:
+    """One process per GPU: RCCL communicator + the one scene broadcast (gs_dist_*, include/gs3d_hip.h)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * Dist.ID_BYTES)()
+        _check(lib().gs_dist_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, world, device=0):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * Dist.ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().gs_dist_create(buf, C.c_int(rank), C.c_int(world), C.c_int(device), C.byref(h)))
+        self._h = h
+        lib().gs_dist_pose_count.restype = C.c_uint64
+
+    @property
+    def rank(self):
+        return lib().gs_dist_rank(self._h)
+
+    @property
+    def world(self):
+        return lib().gs_dist_world(self._h)
+
+    def pose_count(self, poses):
+        return int(lib().gs_dist_pose_count(self._h, C.c_uint64(poses)))
+
+    def broadcast_scene(self, scene=None, root=0):
+        """Root passes its Scene and gets it back; the other ranks get a new Scene holding the received blob."""
+        out = C.c_void_p()
+        _check(lib().gs_dist_broadcast_scene(self._h, scene._h if scene is not None else None, C.c_int(root), C.byref(out)))
+        if scene is not None and out.value == scene._h.value:
+            return scene
+        return Scene(out)
+
+    def close(self):
+        if self._h:
+            lib().gs_dist_destroy(self._h)
             self._h = None
 
     def __del__(self):

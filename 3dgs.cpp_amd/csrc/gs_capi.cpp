@@ -8,7 +8,9 @@
 // pinned memory only to detect instance-buffer overflow (Renderer.cpp:541-563 grows and retries too)
 // or a bin that outgrew the bin-local depth order (then the frame is re-run on the global path).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <rccl/rccl.h>  // types only: the library is loaded on first use (gs_dist_*)
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -109,6 +111,8 @@ struct gs_scene {
     DevBuf<float> owned_blob;
     float* blob = nullptr;  // owned_blob.p or adopted
     DevBuf<float> cov3d;
+    DevBuf<uint16_t> sh16;  // gs_scene_quantize_sh: the SH block as binary16 (preprocess reads it instead)
+    bool sh_half = false;
 
     void finish_load() {  // GSScene::precomputeCov3D, GSScene.cpp:157-184
         cov3d.alloc(6 * n);
@@ -439,17 +443,20 @@ struct FrameBuffers {
     DevBuf<float> depth, radius, bch;
     DevBuf<ushort4> aabb;
     DevBuf<float4> conic_op, uv_rg;
-    // depth sort
-    DevBuf<uint32_t> dkeys[2], dvals[2], tiles_sorted, offsets;
-    DevBuf<uint32_t> block_hist, digit_total, scan_partial;
-    // instances
-    DevBuf<uint32_t> ikeys[2], ivals[2];
-    DevBuf<uint32_t> ranges;
-    DevBuf<uint32_t> sorted, chunk_hist, tile_total;  // hierarchical binning
+    // global depth order (only allocated when that path is taken)
+    DevBuf<uint32_t> dkeys[2], dvals[2];
+    DevBuf<uint32_t> block_hist, digit_total;
+    // two-level binning
+    DevBuf<uint32_t> l1_hist, bin_count;  // [padded bins][level-1 blocks], [1024]
+    DevBuf<uint32_t> cand;                // [capacity] bin-major candidate ids
+    DevBuf<uint32_t> sorted;              // [capacity + 4] per-tile lists, bin-major
+    DevBuf<uint32_t> ranges;              // [T][2]
     DevBuf<gs::Counters> counters;
+    size_t n = 0;
     bool ready = false;
 
-    void init(size_t n, uint32_t capacity) {
+    void init(size_t n_, uint32_t capacity) {
+        n = n_;
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         tiles.alloc(n);
         depth.alloc(n);
@@ -458,29 +465,27 @@ struct FrameBuffers {
         aabb.alloc(n);
         conic_op.alloc(n);
         uv_rg.alloc(n);
-        for (int k = 0; k < 2; ++k) {
-            dkeys[k].alloc(n);
-            dvals[k].alloc(n);
-        }
-        tiles_sorted.alloc(n);
-        offsets.alloc(n);
-        block_hist.alloc(256 * static_cast<size_t>(gs::kSortMaxBlocks));
-        digit_total.alloc(256);
-        scan_partial.alloc(2 * gs::kScanBlocks);
+        l1_hist.alloc(1024 * static_cast<size_t>(gs::bin_level1_blocks(static_cast<uint32_t>(n))));
+        bin_count.alloc(1024);
         counters.alloc(1);
         set_capacity(capacity);
         ready = true;
     }
-    void set_capacity(uint32_t cap) {
+    void ensure_depth_order() {  // the global depth-order path's buffers
+        if (dkeys[0].p) return;
         for (int k = 0; k < 2; ++k) {
-            ikeys[k].alloc(cap);
-            ivals[k].alloc(cap);
-            // a frame whose candidates overflow the capacity leaves a gap of unwritten entries that the bin kernels
-            // still gather through before the frame is re-run: the gap must hold valid Gaussian ids (0), never
-            // whatever hipMalloc handed back
-            HIP_CHECK(hipMemset(ikeys[k].p, 0, static_cast<size_t>(cap) * sizeof(uint32_t)));
-            HIP_CHECK(hipMemset(ivals[k].p, 0, static_cast<size_t>(cap) * sizeof(uint32_t)));
+            dkeys[k].alloc(n);
+            dvals[k].alloc(n);
         }
+        block_hist.alloc(256 * static_cast<size_t>(gs::kSortMaxBlocks));
+        digit_total.alloc(256);
+    }
+    void set_capacity(uint32_t cap) {
+        cand.alloc(cap);
+        // a frame whose candidates overflow the capacity leaves a gap of unwritten entries that k_bin_build still
+        // gathers through before the frame is re-run: the gap must hold valid Gaussian ids (0), never whatever
+        // hipMalloc handed back
+        HIP_CHECK(hipMemset(cand.p, 0, static_cast<size_t>(cap) * sizeof(uint32_t)));
         sorted.alloc(static_cast<size_t>(cap) + 4);  // + 4: a 16-byte list store that starts inside the capacity may end past it
     }
     ~FrameBuffers() {
@@ -496,7 +501,7 @@ struct FrameSlot {
     hipEvent_t done = nullptr;
     gs::Counters* h_counters = nullptr;  // pinned
     bool timed = false;
-    bool bin_local = false;  // the depth-order path this frame took
+    int level = 0;  // the depth-order level this frame ran at (gs_renderer::level)
 };
 
 struct gs_renderer {
@@ -520,13 +525,18 @@ struct gs_renderer {
 
     gs_frame_stats last{};  // stats of the most recently retired frame
 
-    // Which depth-order path a frame takes: bin-local = one in-LDS sort per bin after the binning
-    // (14 kernels per frame), global = the V visible Gaussians ordered first (26 kernels; any bin size).
-    // sort_mode 0 = automatic: bin-local unless the fullest bin of a recent frame does not fit k_bin_sort.
-    int sort_mode = 0;           // 0 auto, 1 global depth order, 2 bin-local (forced: a bin that does not fit is an error)
-    bool bin_local_ok = true;    // automatic mode: no recent frame had a bin beyond kBinSortMax
+    // How a frame's per-tile lists get their depth order.  level 0 / 1: bin-local -- the
+    // workgroup that builds a bin's lists orders its candidates in LDS first (up to 4096 / 16384 per bin; 6 kernels per
+    // frame); level 2: global -- the V visible Gaussians are ordered first (12 more kernels; any bin size).
+    // sort_mode 0 = automatic: start at level 0; a bin that does not fit re-runs the frame one level up; after 32
+    // frames that would have fitted the level below, go back down.
+    int sort_mode = 0;           // 0 auto, 1 global depth order, 2 bin-local (forced: a bin beyond 16384 is an error)
+    int level = 0;
     uint32_t frames_since_fallback = 0;
-    bool use_bin_local() const { return sort_mode == 2 || (sort_mode == 0 && bin_local_ok); }
+    static uint32_t level_limit(int lv) { return lv == 0 ? gs::kBinSortSmall : gs::kBinSortMax; }
+    int frame_level() const { return sort_mode == 1 ? 2 : level; }
+    bool hw_exp = false;         // blend with the hardware's v_exp_f32 instead of the pipeline-defined exp (gs_set_exp_mode)
+    int min_bin_shift = 2;       // GS_BIN_SHIFT: log2 of the smallest bin edge in tiles
     bool have_frame = false;
     uint32_t retries = 0;        // lifetime count of re-run frames (statistics only)
     uint32_t redo_chain = 0;     // consecutive re-runs since a frame last retired cleanly: the runaway guard
@@ -559,6 +569,7 @@ struct gs_renderer {
 
     void init() {
         HIP_CHECK(hipSetDevice(scene->device));
+        HIP_CHECK(gs::bin_prepare_device());
         for (auto& sl : slots) {
             // span timestamps only: no system-scope fence (L2 write-back) between the passes; `done` keeps the fence
             for (auto& e : sl.ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
@@ -619,158 +630,139 @@ struct gs_renderer {
         order_ty = ty;
     }
 
+    // The bin grid of a frame: bins of S x S tiles, at most 32 x 32 of them, padded to a 16- or 32-wide grid.
+    struct BinGeometry {
+        int bin_shift, grid_shift;
+        uint32_t bins_x, bins_y;
+    };
+    BinGeometry bin_geometry(uint32_t tx, uint32_t ty) const {
+        // smallest S >= 4 tiles that keeps the grid within 32 x 32 (more, smaller bins: shorter in-LDS sorts, more
+        // workgroups); GS_BIN_SHIFT (renderer creation) raises it for experiments
+        int s = std::max(2, min_bin_shift);
+        while ((((tx - 1) >> s) + 1) > 32 || (((ty - 1) >> s) + 1) > 32) ++s;
+        if (s > 5) throw Error(GS_ERR_INVALID, "resolution too large for the tile binning (max 16384 x 16384)");
+        BinGeometry g;
+        g.bin_shift = s;
+        g.bins_x = ((tx - 1) >> s) + 1;
+        g.bins_y = ((ty - 1) >> s) + 1;
+        g.grid_shift = (g.bins_x <= 16 && g.bins_y <= 16) ? 4 : 5;
+        return g;
+    }
+
     void enqueue(const gs_uniforms& u, float* d_rgba, uint8_t* d_bgra) {
         HIP_CHECK(hipSetDevice(scene->device));
         FrameSlot& sl = slots[frames_enqueued % kSlots];
         FrameBuffers& fb = sets[frames_enqueued % num_sets];
         hipStream_t stream = fb.stream;
-        auto &tiles = fb.tiles, &tiles_sorted = fb.tiles_sorted, &offsets = fb.offsets, &block_hist = fb.block_hist,
-             &digit_total = fb.digit_total, &scan_partial = fb.scan_partial, &ranges = fb.ranges,
-             &sorted = fb.sorted, &chunk_hist = fb.chunk_hist, &tile_total = fb.tile_total;
-        auto &depth = fb.depth, &radius = fb.radius, &bch = fb.bch;
-        auto &aabb = fb.aabb;
-        auto &conic_op = fb.conic_op, &uv_rg = fb.uv_rg;
-        auto &dkeys = fb.dkeys, &dvals = fb.dvals, &ikeys = fb.ikeys, &ivals = fb.ivals;
-        auto &counters = fb.counters;
         last_set = &fb;
         hipEvent_t* ev = sl.ev;
         const uint32_t n = static_cast<uint32_t>(scene->n);
         const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
         if (tx > 65535 || ty > 65535) throw Error(GS_ERR_INVALID, "resolution too large (tile box is 16-bit)");
         const uint64_t nt = static_cast<uint64_t>(tx) * ty;
-        // bins of S x S tiles, at most 256 of them
-        int bin_shift = 3;
-        while ((((tx - 1) >> bin_shift) + 1) * (((ty - 1) >> bin_shift) + 1) > 256) ++bin_shift;
-        const uint32_t bins_x = ((tx - 1) >> bin_shift) + 1, bins_y = ((ty - 1) >> bin_shift) + 1;
-        const uint32_t bin_tiles = 1u << (2 * bin_shift);
-        if (bin_tiles > 1024) throw Error(GS_ERR_INVALID, "resolution too large for the tile binning (max 8192 x 8192)");
-        const uint32_t max_chunks = capacity / 256 + 256;  // 64-candidate chunks; sized for E1 <= capacity / 4 (flagged otherwise)
-        if (2 * nt > ranges.n || static_cast<size_t>(max_chunks) * bin_tiles > chunk_hist.n) {
-            drain();  // resize: wait for queued frames that still use the old buffers
-            ranges.ensure(2 * nt);
-            tile_total.ensure(nt);
-            chunk_hist.ensure(static_cast<size_t>(max_chunks) * bin_tiles);
+        const BinGeometry geo = bin_geometry(tx, ty);
+        const int lv = frame_level();
+        const bool bin_local = lv < 2;
+        if (2 * nt > fb.ranges.n || (!bin_local && !fb.dkeys[0].p)) {
+            drain();  // (re)allocation: wait for queued frames that still use the old buffers
+            fb.ranges.ensure(2 * nt);
+            if (!bin_local) fb.ensure_depth_order();
         }
         num_tiles = nt;
         ensure_tile_order(tx, ty);
 
-        gs::SceneView sv{scene->blob, scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n))};
-        gs::AttrView av{tiles.p, depth.p, radius.p, aabb.p, conic_op.p, uv_rg.p, bch.p};
-        gs::Counters* cnt = counters.p;
+        gs::SceneView sv{scene->blob, scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n)),
+                          scene->sh_half ? scene->sh16.p : nullptr};
+        gs::AttrView av{fb.tiles.p, fb.depth.p, fb.radius.p, fb.aabb.p, fb.conic_op.p, fb.uv_rg.p, fb.bch.p};
+        gs::Counters* cnt = fb.counters.p;
 
         // the first and the last kernel of the frame clear / publish the counters themselves; the blit nodes (and
         // their fences) are only needed when one of the two is not launched
         const bool fused_counters = n != 0 && u.width != 0 && u.height != 0;
-        if (!fused_counters) HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(gs::Counters), stream));
+        if (!fused_counters) {
+            HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(gs::Counters), stream));
+            HIP_CHECK(hipMemsetAsync(fb.ranges.p, 0, 2 * nt * sizeof(uint32_t), stream));  // no Gaussians: every tile (0, 0)
+        }
         HIP_CHECK(hipEventRecord(ev[0], stream));
-        const bool bin_local = use_bin_local();
-        // bin-local path: preprocess also emits the number of bins each Gaussian touches (index order)
-        gs::launch_preprocess(sv, u, av, cnt, bin_local ? tiles_sorted.p : nullptr, bin_shift, stream);
+        gs::launch_preprocess(sv, u, av, cnt, stream);
         if (timing) HIP_CHECK(hipEventRecord(ev[1], stream));
 
-        const uint32_t* cand = nullptr;  // bin-major candidate ids, (depth, id) order inside a bin
-        if (!bin_local) {
-            // ---- depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
+        if (!bin_local && n != 0) {
+            // ---- global depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
             const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (n + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
-            const uint32_t* kin = reinterpret_cast<const uint32_t*>(depth.p);
+            const uint32_t* kin = reinterpret_cast<const uint32_t*>(fb.depth.p);
             const uint32_t* vin = nullptr;
             for (int pass = 0; pass < 4; ++pass) {
                 gs::RadixPass p{};
                 const int dst = pass & 1;
                 p.keys_in = kin;
                 p.vals_in = vin;
-                p.keys_out = dkeys[dst].p;
-                p.vals_out = dvals[dst].p;
+                p.keys_out = fb.dkeys[dst].p;
+                p.vals_out = fb.dvals[dst].p;
                 p.n_in = &cnt->visible;
                 p.n_static = n;
-                p.tiles = tiles.p;
+                p.tiles = fb.tiles.p;
                 p.n_out = &cnt->visible;
-                p.block_hist = block_hist.p;
-                p.digit_total = digit_total.p;
+                p.block_hist = fb.block_hist.p;
+                p.digit_total = fb.digit_total.p;
                 p.shift = pass * 8;
                 p.bits = 8;
                 p.blocks = blocks;
                 p.first = pass == 0;
-                if (pass == 3) {
-                    p.gather_aabb = aabb.p;  // per Gaussian: how many bins its tile box touches
-                    p.bin_shift = bin_shift;
-                    p.tiles_sorted = tiles_sorted.p;
-                }
                 gs::launch_radix_pass(p, stream);
-                kin = dkeys[dst].p;
-                vin = dvals[dst].p;
+                kin = fb.dkeys[dst].p;
+                vin = fb.dvals[dst].p;
             }
-            depth_order = dvals[1].p;
+            depth_order = fb.dvals[1].p;
         } else {
             depth_order = nullptr;
         }
         if (timing) HIP_CHECK(hipEventRecord(ev[2], stream));
 
-        {
-            // ---- level 1: (bin, Gaussian) candidates, one stable pass by bin ----
-            // global path: over the V visible Gaussians in depth order; bin-local path: over all N in index order
-            // (culled ones count 0 bins), and the scan also counts the visible ones
-            gs::launch_exclusive_scan(tiles_sorted.p, offsets.p, bin_local ? nullptr : &cnt->visible, n, scan_partial.p,
-                                      &cnt->bin_entries, bin_local ? &cnt->visible : nullptr, stream);
-            if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
-            gs::launch_duplicate(bin_local ? nullptr : depth_order, offsets.p, tiles_sorted.p, aabb.p,
-                                 bin_local ? nullptr : &cnt->visible, n, bins_x, bin_shift, capacity, ikeys[0].p,
-                                 ivals[0].p, cnt, stream);
-            if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
-            {
-                gs::RadixPass p{};
-                p.keys_in = ikeys[0].p;
-                p.vals_in = ivals[0].p;
-                p.keys_out = ikeys[1].p;
-                p.vals_out = ivals[1].p;
-                p.n_in = &cnt->bin_entries;
-                p.n_static = capacity;
-                p.block_hist = block_hist.p;
-                p.digit_total = digit_total.p;
-                p.shift = 0;
-                p.bits = 8;
-                p.blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (capacity + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
-                gs::launch_radix_pass(p, stream);
-            }
-            cand = ivals[1].p;
-            if (bin_local) {  // inside each bin: index order -> (depth bits, id) order, in LDS
-                gs::launch_bin_sort(digit_total.p, ivals[1].p, depth.p, ivals[0].p, cnt, bins_x * bins_y, stream);
-                cand = ivals[0].p;
-            }
-            if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
-            // ---- level 2: per-tile counts -> ranges and D (tile_boundary), then the per-tile lists ----
+        if (n != 0) {
             gs::BinLaunch b{};
-            b.cand = cand;
-            b.bin_count = digit_total.p;
-            b.aabb = aabb.p;
-            b.chunk_hist = chunk_hist.p;
-            b.tile_total = tile_total.p;
-            b.ranges = ranges.p;
-            b.sorted_gid = sorted.p;
+            b.order = bin_local ? nullptr : depth_order;
+            b.n_items = bin_local ? nullptr : &cnt->visible;
+            b.n_bound = n;
+            b.tiles = fb.tiles.p;
+            b.aabb = fb.aabb.p;
+            b.depth = fb.depth.p;
+            b.hist = fb.l1_hist.p;
+            b.bin_count = fb.bin_count.p;
+            b.cand = fb.cand.p;
+            b.ranges = fb.ranges.p;
+            b.sorted_gid = fb.sorted.p;
             b.counters = cnt;
             b.capacity = capacity;
             b.tiles_x = tx;
             b.tiles_y = ty;
-            b.bins_x = bins_x;
-            b.bins = bins_x * bins_y;
-            b.shift = bin_shift;
-            b.max_chunks = max_chunks;
-            gs::launch_bin_ranges(b, stream);
-            if (timing) HIP_CHECK(hipEventRecord(ev[6], stream));
-            gs::launch_bin_fill(b, stream);
-            if (timing) HIP_CHECK(hipEventRecord(ev[8], stream));
-            sorted_gid = sorted.p;
+            b.bins_x = geo.bins_x;
+            b.bins_y = geo.bins_y;
+            b.bin_shift = geo.bin_shift;
+            b.grid_shift = geo.grid_shift;
+            // ---- level 1: which Gaussian touches which bin (count + scan, then the per-bin candidate lists) ----
+            gs::launch_bin_level1_count(b, stream);
+            if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
+            gs::launch_bin_level1_scatter(b, stream);
+            if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
+            // ---- level 2: order inside the bin (bin-local path), tile ranges, per-tile lists ----
+            gs::launch_bin_level2(b, lv, stream);
+        } else if (timing) {
+            HIP_CHECK(hipEventRecord(ev[3], stream));
+            HIP_CHECK(hipEventRecord(ev[4], stream));
         }
+        if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
+        sorted_gid = fb.sorted.p;
 
         // ---- blend ----
-        gs::launch_blend(ranges.p, sorted_gid, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
-                         fused_counters ? sl.h_counters : nullptr, stream);
+        gs::launch_blend(fb.ranges.p, sorted_gid, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
+                         fused_counters ? sl.h_counters : nullptr, hw_exp, stream);
         HIP_CHECK(hipEventRecord(ev[7], stream));
         if (!fused_counters) HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipEventRecord(sl.done, stream));
         HIP_CHECK(hipGetLastError());
 
-        sl.bin_local = bin_local;
+        sl.level = lv;
         sl.u = u;
         sl.rgba = d_rgba;
         sl.bgra = d_bgra;
@@ -796,24 +788,29 @@ struct gs_renderer {
             };
             std::vector<Redo> redo;
             uint64_t need = 0;
+            uint32_t fullest = 0;
             bool grow = false, bin_too_big = false;
             for (int k = 0; k < pending; ++k) {
                 FrameSlot& q = slots[(frames_enqueued - pending + k) % kSlots];
                 redo.push_back({q.u, q.rgba, q.bgra});
                 if (q.h_counters->overflow & 1u) {
                     grow = true;
-                    // D instances, or 4 x E1 level-1 candidates (the chunk table is sized from the capacity)
-                    need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, 4ull * q.h_counters->bin_entries));
+                    // D instances and E1 level-1 candidates share the capacity
+                    need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, q.h_counters->bin_entries));
                 }
-                if (q.bin_local && (q.h_counters->overflow & 2u)) bin_too_big = true;
+                if (q.level < 2 && (q.h_counters->overflow & 2u)) bin_too_big = true;
+                fullest = std::max(fullest, q.h_counters->max_bin);
             }
+            const int failed_level = sl.level;
             // the queued frames are dropped from the ring first: whatever is thrown below, the renderer stays usable
             frames_enqueued -= pending;
             pending = 0;
             prev_retired = false;
-            if (bin_too_big) {  // a bin outgrew the in-LDS sort: take the global depth order from here on
-                if (sort_mode == 2) throw Error(GS_ERR_OVERFLOW, "a bin holds more candidates than the bin-local sort can order");
-                bin_local_ok = false;
+            if (bin_too_big) {  // a bin outgrew the in-LDS order of this level: one level up from here on
+                const int wanted = fullest > static_cast<uint32_t>(gs::kBinSortMax) ? 2 : std::max(1, failed_level + 1);
+                if (sort_mode == 2 && wanted >= 2)
+                    throw Error(GS_ERR_OVERFLOW, "a bin holds more candidates than the bin-local sort can order");
+                level = std::max(level, wanted);
                 frames_since_fallback = 0;
             }
             // runaway guard: one frame may need a path fall-back and a few grow steps (each grow is sized from the counts
@@ -829,9 +826,12 @@ struct gs_renderer {
             return;
         }
         redo_chain = 0;
-        if (sort_mode == 0 && !bin_local_ok) {  // back to the bin-local path once the bins have fitted for a while
-            if (sl.h_counters->max_bin <= static_cast<uint32_t>(gs::kBinSortMax) * 7 / 8) {
-                if (++frames_since_fallback >= 32) bin_local_ok = true;
+        if (sort_mode != 1 && level > 0) {  // one level down once the bins have fitted it for a while
+            if (sl.h_counters->max_bin <= level_limit(level - 1) * 7 / 8) {
+                if (++frames_since_fallback >= 32) {
+                    --level;
+                    frames_since_fallback = 0;
+                }
             } else {
                 frames_since_fallback = 0;
             }
@@ -842,7 +842,7 @@ struct gs_renderer {
         st.num_instances = sl.h_counters->instances;
         st.num_bin_entries = sl.h_counters->bin_entries;
         st.max_bin_entries = sl.h_counters->max_bin;
-        st.sort_path = sl.bin_local ? 2u : 1u;
+        st.sort_path = sl.level < 2 ? 2u : 1u;
         st.instance_capacity = capacity;
         auto span = [&](int a, int b) {
             float ms = 0.0f;
@@ -851,12 +851,16 @@ struct gs_renderer {
         };
         st.ms_total = span(0, 7);
         if (sl.timed) {
+            // The reference's six span names (Renderer.cpp:484-526, 580-699).  prefix_sum = the level-1 count + scan,
+            // preprocess_sort = the level-1 scatter (what lands where), sort = the global depth order (when taken) +
+            // k_bin_build.  k_bin_build also produces the tile ranges: tile_boundary.comp's work has no kernel of
+            // its own any more, so that span is 0 by construction.
             st.ms_preprocess = span(0, 1);
-            st.ms_sort = span(1, 2) + span(4, 5) + span(6, 8);
             st.ms_prefix_sum = span(2, 3);
             st.ms_preprocess_sort = span(3, 4);
-            st.ms_tile_boundary = span(5, 6);
-            st.ms_render = span(8, 7);
+            st.ms_sort = span(1, 2) + span(4, 5);
+            st.ms_tile_boundary = 0.0f;
+            st.ms_render = span(5, 7);
         }
         st.retries = retries;
         last = st;
@@ -989,6 +993,42 @@ int gs_scene_blob(const gs_scene* s, float** d_blob, uint64_t* floats) {
 
 uint64_t gs_scene_num_vertices(const gs_scene* s) { return s ? s->n : 0; }
 
+int gs_scene_quantize_sh(gs_scene* s) {
+    return guarded([&] {
+        if (!s) throw Error(GS_ERR_INVALID, "null argument");
+        if (s->sh_half) return;
+        HIP_CHECK(hipSetDevice(s->device));
+        s->sh16.alloc(48 * static_cast<size_t>(s->n));
+        gs::launch_sh_to_half(s->blob, s->sh16.p, static_cast<uint32_t>(s->n), static_cast<uint32_t>(gs::blob_stride(s->n)), nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+        s->sh_half = true;
+    });
+}
+
+int gs_scene_sh_bits(const gs_scene* s) { return s ? (s->sh_half ? 16 : 32) : 0; }
+
+int gs_scene_download_vertex_range(const gs_scene* s, uint64_t first, uint64_t count, float* vertices) {
+    return guarded([&] {
+        if (!s || (!vertices && count)) throw Error(GS_ERR_INVALID, "null argument");
+        if (first > s->n || count > s->n - first) throw Error(GS_ERR_INVALID, "vertex range out of bounds");
+        HIP_CHECK(hipSetDevice(s->device));
+        const size_t st = gs::blob_stride(s->n);
+        std::vector<float> plane(count), sh(48 * static_cast<size_t>(count));
+        auto fetch = [&](int p, int dst_slot) {
+            if (count) HIP_CHECK(hipMemcpy(plane.data(), s->blob + static_cast<size_t>(p) * st + first, count * sizeof(float), hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < count; ++i) vertices[i * gs::host::kVertexFloats + dst_slot] = plane[i];
+        };
+        for (int k = 0; k < 3; ++k) fetch(gs::P_POS + k, k);
+        for (uint64_t i = 0; i < count; ++i) vertices[i * gs::host::kVertexFloats + 3] = 1.0f;
+        for (int k = 0; k < 3; ++k) fetch(gs::P_SCALE + k, 4 + k);
+        fetch(gs::P_OPACITY, 7);
+        for (int k = 0; k < 4; ++k) fetch(gs::P_ROT + k, 8 + k);
+        if (count) HIP_CHECK(hipMemcpy(sh.data(), s->blob + static_cast<size_t>(gs::P_SH) * st + first * 48, sh.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < count; ++i) std::memcpy(vertices + i * gs::host::kVertexFloats + 12, sh.data() + i * 48, 48 * sizeof(float));
+    });
+}
+
 int gs_scene_download_vertices(const gs_scene* s, float* vertices) {
     return guarded([&] {
         if (!s || (!vertices && s->n)) throw Error(GS_ERR_INVALID, "null argument");
@@ -1029,6 +1069,8 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
         auto r = std::make_unique<gs_renderer>();
         r->scene = scene;
         r->init();
+        if (const char* e = std::getenv("GS_EXP_MODE")) r->hw_exp = std::atoi(e) != 0;  // initial gs_set_exp_mode
+        if (const char* e = std::getenv("GS_BIN_SHIFT")) r->min_bin_shift = std::min(5, std::max(2, std::atoi(e)));
         if (const char* e = std::getenv("GS_SORT_PATH")) {  // initial gs_set_sort_path, for hosts that cannot call it (the viewer)
             const int mode = std::atoi(e);
             if (mode < 0 || mode > 2) throw Error(GS_ERR_INVALID, "GS_SORT_PATH must be 0 (auto), 1 (global) or 2 (bin-local)");
@@ -1156,8 +1198,17 @@ int gs_set_sort_path(gs_renderer* r, int mode) {
         if (mode < 0 || mode > 2) throw Error(GS_ERR_INVALID, "sort path must be 0 (auto), 1 (global) or 2 (bin-local)");
         r->drain();
         r->sort_mode = mode;
-        r->bin_local_ok = true;
+        r->level = 0;
         r->frames_since_fallback = 0;
+    });
+}
+
+int gs_set_exp_mode(gs_renderer* r, int mode) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "renderer is null");
+        if (mode < 0 || mode > 1) throw Error(GS_ERR_INVALID, "exp mode must be 0 (pipeline-defined, exact) or 1 (hardware v_exp_f32)");
+        r->drain();
+        r->hw_exp = mode == 1;
     });
 }
 
@@ -1182,17 +1233,39 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
             case GS_STAGE_B: src = r->last_set->bch.p; size = n * 4; break;
             case GS_STAGE_DEPTH_ORDER: src = r->depth_order; size = v * 4; break;
             case GS_STAGE_SORTED_TILE:
-                {   // the tile id of list position i follows from the ranges
+            case GS_STAGE_SORTED_GID:
+            case GS_STAGE_RANGES:
+                {   // The per-tile lists are stored bin-major (the tiles of a bin consecutive, the bins wherever their
+                    // workgroup's atomic add put them); `ranges` holds each tile's (start, end) in that buffer.  The
+                    // reference's buffers are the same lists laid end to end in tile order: the taps present them so.
+                    const uint64_t nt = r->num_tiles;
+                    std::vector<uint32_t> rg(2 * nt);
+                    if (nt) HIP_CHECK(hipMemcpy(rg.data(), r->last_set->ranges.p, rg.size() * 4, hipMemcpyDeviceToHost));
+                    if (stage == GS_STAGE_RANGES) {
+                        if (bytes < nt * 8) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
+                        uint32_t* out = static_cast<uint32_t*>(dst);
+                        uint64_t pos = 0;
+                        for (uint64_t t = 0; t < nt; ++t) {
+                            const uint32_t len = rg[2 * t + 1] - rg[2 * t];
+                            out[2 * t] = len ? static_cast<uint32_t>(pos) : 0u;  // tile_boundary.comp leaves absent tiles (0, 0)
+                            out[2 * t + 1] = len ? static_cast<uint32_t>(pos + len) : 0u;
+                            pos += len;
+                        }
+                        return;
+                    }
                     if (bytes < d * 4) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
-                    std::vector<uint32_t> rg(2 * r->num_tiles);
-                    if (!rg.empty()) HIP_CHECK(hipMemcpy(rg.data(), r->last_set->ranges.p, rg.size() * 4, hipMemcpyDeviceToHost));
+                    std::vector<uint32_t> lists;
+                    if (stage == GS_STAGE_SORTED_GID) {
+                        lists.resize(r->capacity);
+                        HIP_CHECK(hipMemcpy(lists.data(), r->sorted_gid, lists.size() * 4, hipMemcpyDeviceToHost));
+                    }
                     uint32_t* out = static_cast<uint32_t*>(dst);
-                    for (uint64_t t = 0; t < r->num_tiles; ++t)
-                        for (uint64_t i = rg[2 * t]; i < std::min<uint64_t>(rg[2 * t + 1], d); ++i) out[i] = static_cast<uint32_t>(t);
+                    uint64_t pos = 0;
+                    for (uint64_t t = 0; t < nt; ++t)
+                        for (uint64_t i = rg[2 * t]; i < rg[2 * t + 1] && pos < d; ++i)
+                            out[pos++] = stage == GS_STAGE_SORTED_GID ? lists[i] : static_cast<uint32_t>(t);
                     return;
                 }
-            case GS_STAGE_SORTED_GID: src = r->sorted_gid; size = d * 4; break;
-            case GS_STAGE_RANGES: src = r->last_set->ranges.p; size = r->num_tiles * 8; break;
             default: throw Error(GS_ERR_INVALID, "unknown stage");
         }
         if (bytes < size) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
@@ -1201,5 +1274,132 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
 }
 
 void* gs_renderer_stream(gs_renderer* r) { return r ? r->sets[0].stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------
+// Multi-GPU: replicate the scene, shard the poses.  The path shards by frame, so the only collective is
+// one ncclBroadcast of the packed scene blob at load time -- issued here, natively, so that a C++ host of this ABI
+// (the viewer, INTEGRATION.md's RendererHip.cpp) can run one process per GPU without Python.  No reference
+// counterpart: the reference picks one physical device (VulkanContext.cpp:134-178).
+// RCCL is dlopen'ed on first use: single-GPU consumers never load it.
+// ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.lib = ::dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) return x;
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(::dlsym(x.lib, "ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(::dlsym(x.lib, "ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(::dlsym(x.lib, "ncclCommDestroy"));
+        x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(::dlsym(x.lib, "ncclBroadcast"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(::dlsym(x.lib, "ncclGetErrorString"));
+        return x;
+    }();
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString)
+        throw Error(GS_ERR_DEVICE, "librccl.so could not be loaded (multi-GPU entry points need RCCL)");
+    return r;
+}
+void nccl_check(ncclResult_t e, const char* what) {
+    if (e != ncclSuccess) throw Error(GS_ERR_DEVICE, std::string(what) + ": " + rccl().GetErrorString(e));
+}
+}  // namespace
+
+struct gs_dist {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;
+    ~gs_dist() {
+        if (comm) (void)rccl().CommDestroy(comm);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" {
+
+int gs_dist_unique_id(uint8_t id[GS_DIST_ID_BYTES]) {
+    return guarded([&] {
+        if (!id) throw Error(GS_ERR_INVALID, "null argument");
+        static_assert(GS_DIST_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+        ncclUniqueId u;
+        nccl_check(rccl().GetUniqueId(&u), "ncclGetUniqueId");
+        std::memcpy(id, u.internal, GS_DIST_ID_BYTES);
+    });
+}
+
+int gs_dist_create(const uint8_t id[GS_DIST_ID_BYTES], int rank, int world, int device, gs_dist** out) {
+    return guarded([&] {
+        if (!id || !out) throw Error(GS_ERR_INVALID, "null argument");
+        if (world < 1 || rank < 0 || rank >= world) throw Error(GS_ERR_INVALID, "rank / world out of range");
+        select_device(device);
+        auto d = std::make_unique<gs_dist>();
+        d->rank = rank;
+        d->world = world;
+        d->device = device;
+        HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        ncclUniqueId u;
+        std::memcpy(u.internal, id, GS_DIST_ID_BYTES);
+        nccl_check(rccl().CommInitRank(&d->comm, world, u, rank), "ncclCommInitRank");
+        *out = d.release();
+    });
+}
+
+int gs_dist_rank(const gs_dist* d) { return d ? d->rank : -1; }
+int gs_dist_world(const gs_dist* d) { return d ? d->world : 0; }
+
+// pose i is rendered by rank i mod world; the k-th pose of a rank is rank + k * world
+uint64_t gs_dist_pose_count(const gs_dist* d, uint64_t poses) {
+    if (!d || poses <= static_cast<uint64_t>(d->rank)) return 0;
+    return (poses - d->rank + d->world - 1) / d->world;
+}
+
+int gs_dist_broadcast_scene(gs_dist* d, gs_scene* mine, int root, gs_scene** out) {
+    return guarded([&] {
+        if (!d || !out) throw Error(GS_ERR_INVALID, "null argument");
+        if (root < 0 || root >= d->world) throw Error(GS_ERR_INVALID, "root out of range");
+        if (d->rank == root && !mine) throw Error(GS_ERR_INVALID, "the root rank must pass its scene");
+        HIP_CHECK(hipSetDevice(d->device));
+        // (1) the Gaussian count, (2) the packed blob: 11 padded SoA planes + the SH block, one message
+        DevBuf<uint64_t> d_n;
+        d_n.alloc(1);
+        uint64_t n = d->rank == root ? mine->n : 0;
+        HIP_CHECK(hipMemcpyAsync(d_n.p, &n, sizeof n, hipMemcpyHostToDevice, d->stream));
+        nccl_check(rccl().Broadcast(d_n.p, d_n.p, 1, ncclUint64, root, d->comm, d->stream), "ncclBroadcast(count)");
+        HIP_CHECK(hipMemcpyAsync(&n, d_n.p, sizeof n, hipMemcpyDeviceToHost, d->stream));
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
+        if (d->rank == root) {
+            nccl_check(rccl().Broadcast(mine->blob, mine->blob, gs::blob_floats(n), ncclFloat32, root, d->comm, d->stream),
+                       "ncclBroadcast(scene)");
+            HIP_CHECK(hipStreamSynchronize(d->stream));
+            *out = mine;
+            return;
+        }
+        auto s = std::make_unique<gs_scene>();
+        s->device = d->device;
+        s->n = n;
+        s->owned_blob.alloc(gs::blob_floats(n));
+        s->blob = s->owned_blob.p;
+        nccl_check(rccl().Broadcast(s->blob, s->blob, gs::blob_floats(n), ncclFloat32, root, d->comm, d->stream),
+                   "ncclBroadcast(scene)");
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        s->finish_load();  // cov3D is recomputed locally: 24 B / Gaussian of arithmetic instead of 24 B over xGMI
+        *out = s.release();
+    });
+}
+
+void gs_dist_destroy(gs_dist* d) { delete d; }
 
 }  // extern "C"

@@ -11,7 +11,6 @@ namespace gs {
 constexpr int kTile = 16;             // TILE_WIDTH == TILE_HEIGHT, common.glsl:1-2
 constexpr int kSortTileKeys = 2048;   // keys per radix tile (256 threads x 8)
 constexpr int kSortMaxBlocks = 1024;  // fixed sort grid (data-dependent sizes stay on the device)
-constexpr int kScanBlocks = 512;      // fixed scan grid
 
 // Packed scene blob (59 floats per Gaussian + padding): planes 0..10 are SoA with a plane stride of
 // blob_stride(n) = n rounded up to 16 floats -- plane p of Gaussian i is blob[p*stride + i] -- followed by the SH
@@ -26,6 +25,7 @@ struct SceneView {
     const float* cov3d;  // 6 planes of n floats
     uint32_t n;
     uint32_t stride;     // blob_stride(n)
+    const uint16_t* sh16;  // nullable: the SH block as binary16, n x 48 (gs_scene_quantize_sh); read instead of the fp32 one
 };
 
 // Per-frame buffers indexed by Gaussian id.
@@ -48,18 +48,16 @@ struct Counters {
     uint32_t max_bin;    // candidates in the fullest bin
     uint32_t pad;
 };
-constexpr int kBinSortMax = 16384;  // candidates per bin that k_bin_sort can order in LDS (128 KiB of (key, id))
+constexpr int kBinSortSmall = 4096;  // candidates per bin the 256-thread k_bin_build orders in LDS
+constexpr int kBinSortMax = 16384;   // ... and the 1024-thread one (128 KiB of (key, id))
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s);
-// counters (nullable): the kernel clears counters->overflow, so that a frame needs no memset node.
-// nbins (nullable): [N] bins of (1 << bin_shift)^2 tiles touched by each Gaussian's tile box, 0 when culled.
-void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
-                       uint32_t* nbins, int bin_shift, hipStream_t s);
-// Bin-local depth order: bin-major candidate ids (index order inside a bin) -> (depth bits, id) order inside each bin.
-void launch_bin_sort(const uint32_t* bin_count, const uint32_t* ids_in, const float* depth, uint32_t* ids_out,
-                     Counters* counters, uint32_t bins, hipStream_t s);
+// fp32 SH block of the blob -> binary16 (round to nearest even), n x 48 values
+void launch_sh_to_half(const float* blob, uint16_t* sh16, uint32_t n, uint32_t stride, hipStream_t s);
+// counters (nullable): the kernel clears the frame's counters, so that a frame needs no memset node.
+void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters, hipStream_t s);
 
-// Stable LSD radix pass on (u32 key, u32 value) pairs, 8-bit digit at `shift`.
+// Stable LSD radix pass on (u32 key, u32 value) pairs, 8-bit digit at `shift` (the global depth order).
 //   first != 0: the input is (key = bits(depth[i]), value = i) for every i < n_static with tiles[i] != 0
 //               (compaction folded into the first pass); the element count is written to *n_out.
 //   first == 0: the element count is read from *n_in (device memory).
@@ -79,49 +77,43 @@ struct RadixPass {
     int bits;                 // significant bits in this digit (<= 8)
     int blocks;
     int first;
-    const ushort4* gather_aabb;    // last depth pass: per sorted Gaussian, the number of (tile >> bin_shift) bins
-    int bin_shift;                 // its tile box touches ...
-    uint32_t* tiles_sorted;        // ... is written here (may be null)
 };
 void launch_radix_pass(const RadixPass& p, hipStream_t s);
 
-// Exclusive scan of cnt[0..*n) -> off, total -> *total_out (2 kernels, fixed grid).  n == nullptr: n_bound entries.
-// partial: 2 * kScanBlocks uints.  nonzero_out (nullable): number of non-zero entries.
-void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n, uint32_t n_bound,
-                           uint32_t* partial, uint32_t* total_out, uint32_t* nonzero_out, hipStream_t s);
-
-// preprocess_sort.comp counterpart, in depth order: for j < *n_visible, g = order[j], writes
-// tile ids (x outer, y inner) and g at off[j]...  Sets counters->overflow when D > capacity.
-// order == nullptr: g = j; n_visible == nullptr: n_bound entries (entries with a zero count emit nothing).
-void launch_duplicate(const uint32_t* order, const uint32_t* off, const uint32_t* tiles_sorted,
-                      const ushort4* aabb, const uint32_t* n_visible, uint32_t n_bound, uint32_t tiles_x,
-                      int shift, uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,
-                      hipStream_t s);
-
-// Level 2 of the hierarchical binning (k_bin_count, k_bin_scan, k_tile_scan, k_bin_fill): expands the
-// bin-major candidate list into per-tile lists, the tile ranges and D.
+// Two-level binning (gs_kernels.hip): level 1 lists the items (Gaussians in index order, or the visible Gaussians in
+// depth order when `order` is given) per bin of S x S tiles; level 2 turns each bin's list into the per-tile lists
+// (ordering it by (depth bits, id) in LDS first when sort is set), the tile ranges and D.
 struct BinLaunch {
-    const uint32_t* cand;
-    const uint32_t* bin_count;  // [256]
-    const ushort4* aabb;
-    uint32_t* chunk_hist;       // [max_chunks][S*S]
-    uint32_t* tile_total;       // [T], zero-filled by the caller
+    const uint32_t* order;      // null: item p = Gaussian p; else Gaussian order[p]
+    const uint32_t* n_items;    // device-resident item count (null: n_bound)
+    uint32_t n_bound;           // N: sizes the grid and the hist table
+    const uint32_t* tiles;      // [N]
+    const ushort4* aabb;        // [N]
+    const float* depth;         // [N]
+    uint32_t* hist;             // [padded bins][bin_level1_blocks(n_bound)]
+    uint32_t* bin_count;        // [1024]
+    uint32_t* cand;             // [capacity]
     uint32_t* ranges;           // [T][2]
-    uint32_t* sorted_gid;
+    uint32_t* sorted_gid;       // [capacity (+4)]
     Counters* counters;
     uint32_t capacity;
-    uint32_t tiles_x, tiles_y, bins_x, bins;
-    int shift;
-    uint32_t max_chunks;
+    uint32_t tiles_x, tiles_y, bins_x, bins_y;
+    int bin_shift;              // log2 S
+    int grid_shift;             // 4 or 5: padded bin id = by << grid_shift | bx
 };
-void launch_bin_ranges(const BinLaunch& b, hipStream_t s);  // k_bin_count, k_bin_scan, k_tile_scan
-void launch_bin_fill(const BinLaunch& b, hipStream_t s);    // k_bin_fill
+uint32_t bin_level1_blocks(uint32_t n_items);
+hipError_t bin_prepare_device();                                    // once per device, before the first launch_bin_level2
+void launch_bin_level1_count(const BinLaunch& b, hipStream_t s);    // k_l1_hist, k_l1_scan
+void launch_bin_level1_scatter(const BinLaunch& b, hipStream_t s);  // k_l1_scatter
+// variant 0: in-LDS order of up to kBinSortSmall candidates per bin (256-thread workgroups), 1: up to kBinSortMax
+// (1024 threads), 2: no ordering (the candidates arrive in depth order: global path), any bin size
+void launch_bin_level2(const BinLaunch& b, int variant, hipStream_t s);  // k_bin_build
 
 // render.comp counterpart.
 // tile_order[b] = the tile workgroup b renders (a permutation of the tiles)
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
-                  Counters* host_counters /* pinned, nullable: *host_counters = *counters */, hipStream_t s);
+                  Counters* host_counters /* pinned, nullable: *host_counters = *counters */, bool hw_exp, hipStream_t s);
 
 }  // namespace gs

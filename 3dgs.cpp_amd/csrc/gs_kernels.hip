@@ -9,11 +9,14 @@
 //   k_cov3d        precomp_cov3d.comp:25-47, common.glsl:51-75
 //   k_preprocess   preprocess.comp:34-183
 //   k_radix_*      sort/hist.comp + sort/sort.comp (result: stable ascending order)
-//   k_scan_*       prefix_sum.comp:32-59 (result: prefix sums)
-//   k_duplicate    preprocess_sort.comp:31-61
-//   k_bin_*, k_tile_scan   preprocess_sort.comp + the tile part of the sort + tile_boundary.comp:22-50
+//   k_l1_*         prefix_sum.comp:32-59 + preprocess_sort.comp:31-61 (which Gaussian lands in which part of the screen)
+//   k_bin_build    the sort's result inside a bin + tile_boundary.comp:22-50 + the sorted payload
 //   k_blend        render.comp:30-99
 #include "gs_kernels.h"
+
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
 
 namespace gs {
 
@@ -119,6 +122,18 @@ __global__ __launch_bounds__(BLOCK) void k_cov3d(const float* __restrict__ blob,
     cov3d[5 * NC + i] = C.c[2][2];
 }
 
+// Opt-in SH quantisation: the fp32 SH block -> binary16, round to nearest even.
+__global__ __launch_bounds__(BLOCK) void k_sh_to_half(const float* __restrict__ sh, uint16_t* __restrict__ out, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < count) out[i] = __half_as_ushort(__float2half_rn(sh[i]));
+}
+void launch_sh_to_half(const float* blob, uint16_t* sh16, uint32_t n, uint32_t stride, hipStream_t s) {
+    if (n == 0) return;
+    const uint64_t count = 48ull * n;
+    hipLaunchKernelGGL(k_sh_to_half, dim3((uint32_t)((count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                       blob + (size_t)P_SH * stride, sh16, count);
+}
+
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_cov3d, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob, cov3d, n, stride);
@@ -137,16 +152,17 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * 
 struct PreUniforms {
     gs_uniforms u;
     Counters* counters;  // nullable
-    uint32_t* nbins;     // nullable: [N] number of S x S-tile bins the tile box touches (0 when culled), index order
-    int bin_shift;
 };
 
 __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms pu, AttrView av) {
     const gs_uniforms& u = pu.u;
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= sv.n) return;
-    if (i == 0 && pu.counters) {  // first kernel of the frame: the counters that are not plainly overwritten
+    if (i == 0 && pu.counters) {  // first kernel of the frame: the counters the later kernels accumulate into
+        pu.counters->visible = 0;
+        pu.counters->instances = 0;
         pu.counters->overflow = 0;
+        pu.counters->bin_entries = 0;
         pu.counters->max_bin = 0;
     }
     const size_t N = sv.stride, NC = sv.n;
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
     const float py = blob[(P_POS + 1) * N + i];
     const float pz = blob[(P_POS + 2) * N + i];
 
-    uint32_t num_tiles = 0, num_bins = 0;
+    uint32_t num_tiles = 0;
     do {
         // preprocess.comp:130-135 (position.w == 1)
         float p_hom[4], p_view[3];
@@ -265,7 +281,19 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         // the 48 SH floats of a Gaussian are contiguous (192 B = three 64-byte lines): only lanes that
         // survived every cull fetch them, so SH traffic is 192 B per VISIBLE Gaussian
         float sh[48];
-        {
+        if (sv.sh16) {  // opt-in binary16 storage (gs_scene_quantize_sh): 96 B per visible Gaussian, widened exactly
+            const uint4* __restrict__ shv = reinterpret_cast<const uint4*>(sv.sh16) + (size_t)i * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const uint4 t = shv[q];
+                const uint32_t wds[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sh[8 * q + 2 * k + 0] = __half2float(__ushort_as_half((unsigned short)(wds[k] & 0xFFFFu)));
+                    sh[8 * q + 2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(wds[k] >> 16)));
+                }
+            }
+        } else {
             const float4* __restrict__ shv = reinterpret_cast<const float4*>(blob + (size_t)P_SH * N) + (size_t)i * 12;
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
@@ -308,8 +336,6 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         if (rgb[0] < 0.0f) rgb[0] = 0.0f;
 
         num_tiles = nt;
-        num_bins = (uint32_t)(((bx1 - 1) >> pu.bin_shift) - (bx0 >> pu.bin_shift) + 1) *
-                   (uint32_t)(((by1 - 1) >> pu.bin_shift) - (by0 >> pu.bin_shift) + 1);
         av.depth[i] = p_view[2];
         av.radius[i] = radii;
         av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1,
@@ -319,17 +345,14 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         av.b[i] = rgb[2];
     } while (false);
     av.tiles[i] = num_tiles;  // :128 / :176
-    if (pu.nbins) pu.nbins[i] = num_bins;
 }
 
 void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
-                       uint32_t* nbins, int bin_shift, hipStream_t s) {
+                       hipStream_t s) {
     if (sv.n == 0) return;
     PreUniforms pu;
     pu.u = u;
     pu.counters = counters;
-    pu.nbins = nbins;
-    pu.bin_shift = bin_shift;
     hipLaunchKernelGGL(k_preprocess, dim3((sv.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, sv, pu, av);
 }
 
@@ -382,9 +405,6 @@ struct RadixArgs {
     uint32_t* n_out;
     uint32_t* block_hist;
     uint32_t* digit_total;
-    const ushort4* gather_aabb;
-    uint32_t* tiles_sorted;
-    int bin_shift;
     int shift;
     uint32_t mask;
     int blocks;
@@ -549,12 +569,6 @@ __global__ __launch_bounds__(BLOCK) void k_radix_scatter(RadixArgs a) {
                 const uint32_t dst = s_base[d] + (slot - s_texcl[d]);
                 a.keys_out[dst] = k2;
                 a.vals_out[dst] = v2;
-                if (a.tiles_sorted) {  // number of S x S-tile bins the Gaussian's tile box touches
-                    const ushort4 bx = a.gather_aabb[v2];
-                    const uint32_t nx = ((bx.z - 1u) >> a.bin_shift) - (bx.x >> a.bin_shift) + 1u;
-                    const uint32_t ny = ((bx.w - 1u) >> a.bin_shift) - (bx.y >> a.bin_shift) + 1u;
-                    a.tiles_sorted[dst] = nx * ny;
-                }
             }
         }
         __syncthreads();
@@ -575,9 +589,6 @@ void launch_radix_pass(const RadixPass& p, hipStream_t s) {
     a.n_out = p.n_out;
     a.block_hist = p.block_hist;
     a.digit_total = p.digit_total;
-    a.gather_aabb = p.gather_aabb;
-    a.bin_shift = p.bin_shift;
-    a.tiles_sorted = p.tiles_sorted;
     a.shift = p.shift;
     a.mask = (1u << p.bits) - 1u;
     a.blocks = p.blocks;
@@ -593,252 +604,41 @@ void launch_radix_pass(const RadixPass& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Exclusive scan (reduce, then downsweep with the spine folded in), fixed grid of kScanBlocks.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
-    // contiguous, 1024-aligned slices
-    const uint32_t chunks = (n + 1023) / 1024;
-    lo = (uint32_t)((uint64_t)blockIdx.x * chunks / kScanBlocks) * 1024u;
-    hi = (uint32_t)((uint64_t)(blockIdx.x + 1) * chunks / kScanBlocks) * 1024u;
-    if (hi > n) hi = n;
-    if (lo > n) lo = n;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_scan_reduce(const uint32_t* __restrict__ cnt, const uint32_t* n_ptr,
-                                                       uint32_t n_bound, uint32_t* partial) {
-    __shared__ uint32_t scratch[8];
-    uint32_t n = n_ptr ? *n_ptr : n_bound;
-    if (n > n_bound) n = n_bound;
-    uint32_t lo, hi;
-    scan_range(n, lo, hi);
-    uint32_t sum = 0, nonzero = 0;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += BLOCK) {
-        const uint32_t c = cnt[i];
-        sum += c;
-        nonzero += c != 0 ? 1u : 0u;
-    }
-    uint32_t total, total_nz;
-    block_excl_scan<BLOCK>(sum, scratch, &total);
-    block_excl_scan<BLOCK>(nonzero, scratch, &total_nz);
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = total;
-        partial[kScanBlocks + blockIdx.x] = total_nz;  // second half: how many entries of the slice are non-zero
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_scan_down(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
-                                                     const uint32_t* n_ptr, uint32_t n_bound,
-                                                     const uint32_t* partial, uint32_t* total_out,
-                                                     uint32_t* nonzero_out) {
-    __shared__ uint32_t scratch[8];
-    uint32_t n = n_ptr ? *n_ptr : n_bound;
-    if (n > n_bound) n = n_bound;
-    uint32_t lo, hi;
-    scan_range(n, lo, hi);
-    static_assert(kScanBlocks == 2 * BLOCK, "the folded spine reads two partials per thread");
-    // spine folded in: every block sums the kScanBlocks (= 2 x 256) block partials before its own (2 KB, L2)
-    uint32_t running, grand;
-    {
-        const uint32_t p0 = partial[threadIdx.x], p1 = partial[threadIdx.x + BLOCK];
-        const uint32_t mine = (threadIdx.x < blockIdx.x ? p0 : 0u) + (threadIdx.x + BLOCK < blockIdx.x ? p1 : 0u);
-        block_excl_scan<BLOCK>(mine, scratch, &running);
-        block_excl_scan<BLOCK>(p0 + p1, scratch, &grand);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = grand;
-        if (nonzero_out && blockIdx.x == 0) {  // uniform branch
-            uint32_t nz;
-            block_excl_scan<BLOCK>(partial[kScanBlocks + threadIdx.x] + partial[kScanBlocks + BLOCK + threadIdx.x], scratch, &nz);
-            if (threadIdx.x == 0) *nonzero_out = nz;
-        }
-    }
-    for (uint32_t base = lo; base < hi; base += 1024) {
-        const uint32_t i0 = base + threadIdx.x * 4;  // base is 1024-aligned -> 16-byte aligned
-        uint32_t v[4] = {0, 0, 0, 0};
-        if (i0 + 3 < hi) {
-            const uint4 q = *reinterpret_cast<const uint4*>(cnt + i0);
-            v[0] = q.x;
-            v[1] = q.y;
-            v[2] = q.z;
-            v[3] = q.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (i0 + k < hi) v[k] = cnt[i0 + k];
-        }
-        const uint32_t sum = v[0] + v[1] + v[2] + v[3];
-        uint32_t total;
-        uint32_t excl = running + block_excl_scan<BLOCK>(sum, scratch, &total);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i0 + k < hi) off[i0 + k] = excl;
-            excl += v[k];
-        }
-        running += total;
-    }
-}
-
-void launch_exclusive_scan(const uint32_t* cnt, uint32_t* off, const uint32_t* n, uint32_t n_bound,
-                           uint32_t* partial, uint32_t* total_out, uint32_t* nonzero_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_reduce, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, n, n_bound, partial);
-    hipLaunchKernelGGL(k_scan_down, dim3(kScanBlocks), dim3(BLOCK), 0, s, cnt, off, n, n_bound, partial, total_out,
-                       nonzero_out);
-}
-
-// ---------------------------------------------------------------------------------------
-// duplicate: one lane per visible Gaussian (in depth order); boxes of >= 64 tiles are written
-// by the whole wave so that the widest splats do not serialise one lane.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_duplicate(const uint32_t* __restrict__ order,
-                                                     const uint32_t* __restrict__ off,
-                                                     const uint32_t* __restrict__ tiles_sorted,
-                                                     const ushort4* __restrict__ aabb, const uint32_t* n_visible,
-                                                     uint32_t n_bound, uint32_t tiles_x, int shift, uint32_t capacity,
-                                                     uint32_t* __restrict__ inst_tile,
-                                                     uint32_t* __restrict__ inst_gid, Counters* counters) {
-    uint32_t n = n_visible ? *n_visible : n_bound;  // null: every Gaussian, in index order (bin-local path)
-    if (n > n_bound) n = n_bound;
-    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && counters->bin_entries > capacity) counters->overflow |= 1u;
-    if (blockIdx.x * BLOCK >= n) return;
-
-    bool valid = j < n;
-    uint32_t g = 0, o = 0, cnt = 0;
-    ushort4 box = make_ushort4(0, 0, 0, 0);
-    if (valid) {
-        g = order ? order[j] : j;
-        o = off[j];
-        cnt = tiles_sorted[j];
-        if (cnt) box = aabb[g];
-        if (shift) {  // tile box -> box of (tile >> shift) bins, upper bounds exclusive
-            box.z = (unsigned short)(((box.z - 1u) >> shift) + 1u);
-            box.w = (unsigned short)(((box.w - 1u) >> shift) + 1u);
-            box.x = (unsigned short)(box.x >> shift);
-            box.y = (unsigned short)(box.y >> shift);
-        }
-        if ((uint64_t)o + cnt > capacity) valid = false;  // overflow: frame is re-run after growing
-    }
-    const bool big = valid && cnt >= WAVE;
-    uint64_t bm = __ballot(big);
-    while (bm) {
-        const int src = __ffsll((unsigned long long)bm) - 1;
-        bm &= bm - 1;
-        const uint32_t x0 = __shfl((uint32_t)box.x, src, WAVE), y0 = __shfl((uint32_t)box.y, src, WAVE);
-        const uint32_t y1 = __shfl((uint32_t)box.w, src, WAVE);
-        const uint32_t c = __shfl(cnt, src, WAVE), ob = __shfl(o, src, WAVE), gs_ = __shfl(g, src, WAVE);
-        const uint32_t h = y1 - y0;
-        for (uint32_t k = lane; k < c; k += WAVE) {
-            const uint32_t xi = k / h, yi = k - xi * h;  // x outer, y inner (preprocess_sort.comp:47-48)
-            inst_tile[ob + k] = (x0 + xi) + (y0 + yi) * tiles_x;
-            inst_gid[ob + k] = gs_;
-        }
-    }
-    if (valid && !big) {
-        uint32_t ind = o;
-        for (uint32_t x = box.x; x < box.z; ++x)
-            for (uint32_t y = box.y; y < box.w; ++y) {
-                inst_tile[ind] = x + y * tiles_x;
-                inst_gid[ind] = g;
-                ++ind;
-            }
-    }
-}
-
-void launch_duplicate(const uint32_t* order, const uint32_t* off, const uint32_t* tiles_sorted,
-                      const ushort4* aabb, const uint32_t* n_visible, uint32_t n_bound, uint32_t tiles_x,
-                      int shift, uint32_t capacity, uint32_t* inst_tile, uint32_t* inst_gid, Counters* counters,
-                      hipStream_t s) {
-    if (n_bound == 0) return;
-    hipLaunchKernelGGL(k_duplicate, dim3((n_bound + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, order, off,
-                       tiles_sorted, aabb, n_visible, n_bound, tiles_x, shift, capacity, inst_tile, inst_gid, counters);
-}
-
-// ---------------------------------------------------------------------------------------
-// Hierarchical binning: per-tile lists without sorting the D instances.
+// Two-level binning: per-tile depth-ordered lists without sorting the D instances.
 //
-// The screen is cut into <= 256 bins of S x S tiles.  Level 1 (existing kernels) lists, per bin, the
-// Gaussians whose tile box touches it, in depth order: a scan, k_duplicate on bin boxes and ONE stable
-// 8-bit radix pass over E1 ~ 1.2 V entries -- instead of two passes over D ~ 10 V.  Level 2 (below)
-// expands each bin's list into its S*S tiles: 256-candidate chunks count per tile (k_bin_count), the
-// per-tile counts are scanned over chunks and over tiles (k_bin_scan, k_tile_scan -> the ranges and D),
-// and k_bin_fill writes every Gaussian id at  range.start + chunk prefix + rank-in-chunk,  the rank
-// coming from a wave64 ballot per tile.  Depth order is preserved at every step (stable radix pass,
-// chunks in order, lanes in order), so each tile's list equals the reference's stably sorted payload.
-// The instance data moved through HBM drops from ~48 B to ~4 B per instance.
+// The screen is cut into a grid of at most 32 x 32 bins of S x S tiles (bin id = by * GW + bx on a padded grid of
+// width GW = 16 or 32).  LEVEL 1 lists, per bin, the items whose tile box touches it, in item order (items are the
+// Gaussians in index order on the bin-local path, or the visible Gaussians in depth order on the global path):
+//     k_l1_hist     per block of 1024 items, how many touch each bin           hist[bin][block]
+//     k_l1_scan     per bin, exclusive prefix over the blocks + the bin total  (one workgroup per bin)
+//     k_l1_scatter  each block appends its items to the bins' lists at  bin offset + block prefix + rank in block
+// LEVEL 2 (k_bin_build, one 1024-thread workgroup per bin) puts the bin's candidates into (depth bits, id) order in
+// LDS (bin-local path; on the global path they already are), counts how many cover each of the bin's S*S tiles,
+// takes a segment of the list buffer for the bin (one atomic add: the lists are bin-major, the tiles of a bin
+// consecutive), writes the tile ranges, and appends every candidate to the lists of the tiles it covers, in order.
+//
+// Both levels use the same primitive.  A wave takes 64 consecutive items; lane k turns item k's box into coverage
+// words over the cells (bins at level 1, tiles at level 2); a 64 x 64 bit-matrix transpose across the wave gives
+// lane c the column of cell c: which of the 64 items cover it, in item order.  Counting is a popcount; appending
+// walks the set bits.  Order is preserved at every step (blocks in order, waves in order, lanes in order), so each
+// tile's list equals the reference's stably sorted payload (preprocess_sort.comp + the 8 radix passes) and the
+// ranges equal tile_boundary.comp's up to the position of the lists in the buffer -- while the instance data moved
+// through HBM drops from ~ 8 passes x 24 B x D to ~ 4 B x D.
 // ---------------------------------------------------------------------------------------
-struct BinArgs {
-    const uint32_t* cand;         // bin-major, depth-ordered Gaussian ids (level-1 output)
-    const uint32_t* bin_count;    // [256] candidates per bin (the radix pass's digit totals)
-    const ushort4* aabb;
-    uint32_t* chunk_hist;         // [chunk][S*S]: count, then exclusive prefix over the bin's chunks
-    uint32_t* tile_total;         // [T]
-    uint32_t* ranges;             // [T][2]
-    uint32_t* sorted_gid;         // [capacity]
-    Counters* counters;
-    uint32_t capacity;
-    uint32_t tiles_x, tiles_y, bins_x;
-    int shift;                    // log2(S)
-    uint32_t max_chunks;
-};
 
-constexpr int kBinChunk = 64;     // candidates per chunk (= one wave; the four waves of a workgroup are independent)
-constexpr int kBinGrid = 2048;    // persistent grid (x4 waves) striding over the device-resident chunk count
-
-// Offsets and chunk prefixes of all bins (once per block); returns the total number of chunks.
-__device__ __forceinline__ uint32_t bin_prepare(const BinArgs& a, uint32_t* s_off, uint32_t* s_cpre, uint32_t* scratch) {
-    const int tid = threadIdx.x;
-    const uint32_t c = a.bin_count[tid];
-    uint32_t total, total_chunks;
-    const uint32_t off = block_excl_scan<BLOCK>(c, scratch, &total);
-    const uint32_t nch = (c + kBinChunk - 1) / kBinChunk;
-    const uint32_t cpre = block_excl_scan<BLOCK>(nch, scratch, &total_chunks);
-    s_off[tid] = off;
-    s_cpre[tid] = cpre;
-    __syncthreads();
-    return __builtin_amdgcn_readfirstlane(total_chunks);  // same in every lane: keep it scalar
-}
-
-// chunk id -> (bin, first candidate, candidate count); uniform binary search over the 256 chunk prefixes
-__device__ __forceinline__ void bin_locate(const BinArgs& a, const uint32_t* s_off, const uint32_t* s_cpre, uint32_t chunk,
-                                           uint32_t& bin, uint32_t& first, uint32_t& count) {
-    uint32_t lo = 0, hi = 256;  // last bin whose chunk prefix is <= chunk and that owns chunks
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (s_cpre[mid] <= chunk) lo = mid; else hi = mid;
-    }
-    // empty bins share the prefix of their successor: step forward to the owner of this chunk
-    while (a.bin_count[lo] == 0) ++lo;
-    bin = lo;
-    const uint32_t q = chunk - s_cpre[bin];
-    first = s_off[bin] + q * kBinChunk;
-    const uint32_t end = s_off[bin] + a.bin_count[bin];
-    count = min((uint32_t)kBinChunk, end - first);
-}
-
-// candidate's tile box clipped to the bin, in bin-local tile coordinates (upper bounds exclusive)
-__device__ __forceinline__ void bin_local_box(const BinArgs& a, uint32_t bin, ushort4 box, int& lx0, int& ly0, int& lx1,
-                                              int& ly1) {
-    const int S = 1 << a.shift;
-    const int ox = (int)(bin % a.bins_x) << a.shift, oy = (int)(bin / a.bins_x) << a.shift;
-    lx0 = max((int)box.x, ox) - ox;
-    ly0 = max((int)box.y, oy) - oy;
-    lx1 = min((int)box.z, ox + S) - ox;
-    ly1 = min((int)box.w, oy + S) - oy;
-}
-
-// Coverage of a candidate's bin-local box as bit masks over the bin's S*S tiles: tile t = y*S + x lives in
-// bit (t % 64) of word (t / 64), i.e. lane (t % 64) "owns" tile t in register slot t / 64.  R = S*S/64 words.
+// Coverage of a box [x0,x1) x [y0,y1) as bit masks over a (1 << shift)-wide grid of cells: cell c = y * W + x lives
+// in bit (c % 64) of word (c / 64), i.e. lane (c % 64) "owns" cell c in register slot c / 64.
 template <int R>
-__device__ __forceinline__ void bin_cover_masks(int shift, int lx0, int ly0, int lx1, int ly1, uint64_t (&m)[R]) {
-    const int S = 1 << shift;
-    const int rows_per_word = 64 >> shift;  // 8, 4, 2 for S = 8, 16, 32
-    const uint64_t rowbits = lx1 > lx0 ? ((lx1 - lx0 >= 64 ? ~0ull : ((1ull << (lx1 - lx0)) - 1ull)) << lx0) : 0ull;
+__device__ __forceinline__ void cover_masks(int shift, int x0, int y0, int x1, int y1, uint64_t (&m)[R]) {
+    const int W = 1 << shift;
+    const int rows_per_word = 64 >> shift;  // 16, 8, 4, 2 for W = 4, 8, 16, 32
+    const uint64_t rowbits = x1 > x0 ? ((x1 - x0 >= 64 ? ~0ull : ((1ull << (x1 - x0)) - 1ull)) << x0) : 0ull;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         uint64_t w = 0;
         for (int yy = 0; yy < rows_per_word; ++yy) {
             const int y = r * rows_per_word + yy;
-            if (y >= ly0 && y < ly1) w |= rowbits << (yy * S);
+            if (y >= y0 && y < y1) w |= rowbits << (yy * W);
         }
         m[r] = w;
     }
@@ -869,422 +669,596 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, uint32_t lane) 
     return ((uint64_t)hi << 32) | lo;
 }
 
-// Per-wave expansion of its 64 candidates into the tiles of the bin.  Lane k enters with candidate k's coverage
-// words; a bit-matrix transpose per word puts lane t in possession of tile t's column: which of the 64
-// candidates cover it, in candidate (= depth) order.  Counting is a popcount.  Filling walks each lane's own
-// set bits: "k = lowest set bit, store ids[k] at cursor, cursor++", for as many rounds as the fullest tile of
-// the chunk needs (typically 8-16, where a candidate-major walk issues 64 mostly-empty scattered stores: the
-// scattered-store issue rate is what bounds this kernel).  The store is a raw buffer store whose offset is
-// forced out of range on lanes that have run dry, so the hardware's bounds check drops it (and enforces the
-// list capacity) without a branch.
-template <int R, bool FILL>
-__device__ __forceinline__ void bin_walk(const uint64_t (&m)[R], uint32_t (&cursor)[R], __amdgpu_buffer_rsrc_t out,
-                                         const uint32_t* __restrict__ ids /* wave-private [64]: the candidates' ids */) {
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
+// Lane c owns a cell's column `col` (which of the wave's 64 items cover the cell, bit k = item k) and the cell's
+// list cursor `cur` (in entries).  Appends ids[k] for every set bit, in order: up to four ids per lane and round,
+// written with ONE store of 4..16 bytes -- every lane's store is its own request to the L2 (a different line per
+// lane), so what bounds this is the number of requests, not of bytes.  One store instruction per size; lanes of
+// another size are given an out-of-range offset, which the hardware's bounds check drops (the same check enforces
+// the list capacity) without a branch.
+__device__ __forceinline__ void walk_column(uint64_t col, uint32_t cur, __amdgpu_buffer_rsrc_t out,
+                                            const uint32_t* __restrict__ ids /* wave-private [64] */) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    while (__builtin_amdgcn_ballot_w64(col != 0) != 0) {
+        const uint32_t pc = (uint32_t)__popcll(col);
+        const uint32_t cnt = pc < 4u ? pc : 4u;
+        uint32_t id[4];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (R > 1 && __builtin_amdgcn_ballot_w64(m[r] != 0) == 0) {  // uniform: no candidate touches this word
-            if (!FILL) cursor[r] = 0;
-            continue;
+        for (int j = 0; j < 4; ++j) {  // an exhausted column reads slot 63 and drops the value below
+            id[j] = ids[(uint32_t)(__ffsll((unsigned long long)col) - 1) & 63u];
+            col &= col - 1;
         }
-        uint64_t col = wave_transpose64(m[r], lane);
-        if (!FILL) {
-            cursor[r] = (uint32_t)__popcll(col);
-            continue;
-        }
-        // up to four ids per lane and round, written with ONE store of 4..16 bytes: the lists are written at ~1 TB/s
-        // because every lane's store is its own request to the L2 (a different line per lane), so what counts is the
-        // number of requests, not of bytes.  One store instruction per size; lanes of another size are out of range.
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        uint32_t cur = cursor[r];
-        while (__builtin_amdgcn_ballot_w64(col != 0) != 0) {
-            const uint32_t pc = (uint32_t)__popcll(col);
-            const uint32_t cnt = pc < 4u ? pc : 4u;
-            uint32_t id[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {  // an exhausted column reads slot 63 and drops the value below
-                id[j] = ids[(uint32_t)(__ffsll((unsigned long long)col) - 1) & 63u];
-                col &= col - 1;
-            }
-            const uint32_t off = cur * 4u;
-            __builtin_amdgcn_raw_buffer_store_b32(id[0], out, cnt == 1u ? off : 0xFFFFFFFFu, 0, 0);
-            u32x2 v2 = {id[0], id[1]};
-            __builtin_amdgcn_raw_buffer_store_b64(v2, out, cnt == 2u ? off : 0xFFFFFFFFu, 0, 0);
-            u32x3 v3 = {id[0], id[1], id[2]};
-            __builtin_amdgcn_raw_buffer_store_b96(v3, out, cnt == 3u ? off : 0xFFFFFFFFu, 0, 0);
-            u32x4 v4 = {id[0], id[1], id[2], id[3]};
-            __builtin_amdgcn_raw_buffer_store_b128(v4, out, cnt == 4u ? off : 0xFFFFFFFFu, 0, 0);
-            cur += cnt;
-        }
+        const uint32_t off = cur * 4u;
+        __builtin_amdgcn_raw_buffer_store_b32(id[0], out, cnt == 1u ? off : 0xFFFFFFFFu, 0, 0);
+        u32x2 v2 = {id[0], id[1]};
+        __builtin_amdgcn_raw_buffer_store_b64(v2, out, cnt == 2u ? off : 0xFFFFFFFFu, 0, 0);
+        u32x3 v3 = {id[0], id[1], id[2]};
+        __builtin_amdgcn_raw_buffer_store_b96(v3, out, cnt == 3u ? off : 0xFFFFFFFFu, 0, 0);
+        u32x4 v4 = {id[0], id[1], id[2], id[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v4, out, cnt == 4u ? off : 0xFFFFFFFFu, 0, 0);
+        cur += cnt;
     }
 }
 
+constexpr int kL1Items = 1024;   // items per level-1 block: 16 chunks of 64, four per wave of a 256-thread workgroup
+constexpr int kL1Chunks = kL1Items / WAVE;
+constexpr int kL1PerWave = kL1Chunks / (BLOCK / WAVE);
+
+struct BinGrid {
+    uint32_t tiles_x, tiles_y;  // tiles of the screen
+    uint32_t bins_x, bins_y;    // bins of the screen (<= 32 each)
+    int bin_shift;              // log2 S: a bin is S x S tiles
+    int grid_shift;             // log2 GW: padded bin id = by << grid_shift | bx
+};
+
+struct L1Args {
+    BinGrid g;
+    const uint32_t* order;      // null: item p is Gaussian p; else item p is Gaussian order[p] (depth order)
+    const uint32_t* n_items;    // device-resident item count; null: n_bound
+    uint32_t n_bound;
+    const uint32_t* tiles;      // [N] tiles_overlap (0 = culled)
+    const ushort4* aabb;        // [N] tile boxes
+    uint32_t* hist;             // [bins (padded)][nblk]
+    uint32_t* bin_count;        // [bins (padded)]
+    uint32_t* cand;             // [capacity] bin-major candidate Gaussian ids
+    Counters* counters;
+    uint32_t capacity;
+    uint32_t nblk;
+};
+
+__device__ __forceinline__ bool bin_on_screen(const BinGrid& g, uint32_t bin) {
+    return (bin & ((1u << g.grid_shift) - 1u)) < g.bins_x && (bin >> g.grid_shift) < g.bins_y;
+}
+
+// item p -> Gaussian id and its box in bin coordinates packed x0 | y0 << 8 | x1 << 16 | y1 << 24 (upper bounds
+// exclusive; 0 = culled or absent: covers nothing)
+__device__ __forceinline__ uint32_t l1_item(const L1Args& a, uint32_t p, uint32_t n, uint32_t& box_out) {
+    uint32_t gid = 0;
+    box_out = 0;
+    if (p < n) {
+        gid = a.order ? a.order[p] : p;
+        if (a.tiles[gid] != 0) {
+            const ushort4 box = a.aabb[gid];
+            const uint32_t x0 = box.x >> a.g.bin_shift, y0 = box.y >> a.g.bin_shift;
+            const uint32_t x1 = ((box.z - 1u) >> a.g.bin_shift) + 1u, y1 = ((box.w - 1u) >> a.g.bin_shift) + 1u;
+            box_out = x0 | (y0 << 8) | (x1 << 16) | (y1 << 24);
+        }
+    }
+    return gid;
+}
 template <int R>
-__global__ __launch_bounds__(BLOCK) void k_bin_count(BinArgs a) {
-    __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
-    uint32_t total_chunks = bin_prepare(a, s_off, s_cpre, scratch);
+__device__ __forceinline__ void packed_cover_masks(int shift, uint32_t box, uint64_t (&m)[R]) {
+    cover_masks<R>(shift, (int)(box & 255u), (int)((box >> 8) & 255u), (int)((box >> 16) & 255u), (int)(box >> 24), m);
+}
+
+// Wave w of the block takes chunks 4w .. 4w + 3 (consecutive items): all loads of its four chunks are issued before
+// the first is used, and 8 such blocks are resident per CU -- the kernels are a handful of dependent memory round
+// trips each, so what matters is how many of them are in flight.
+template <int R1>
+__global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
+    constexpr int NB = 64 * R1;
+    __shared__ uint32_t s_hist[NB];
+    __shared__ uint32_t s_vis;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    constexpr int SS = 64 * R;
-    if (total_chunks > a.max_chunks) {  // chunk table too small: flag, stay in bounds; the frame is re-run
-        if (blockIdx.x == 0 && tid == 0) a.counters->overflow |= 1u;
-        total_chunks = a.max_chunks;
-    }
-    // the chunk loop is per wave: tell the compiler its control values are wave-uniform (scalar registers)
-    const uint32_t wu = __builtin_amdgcn_readfirstlane((uint32_t)w);
-    // chunk -> wave: groups of 16 consecutive chunks (1024 candidates, nearly always one bin) stay on one XCD
-    // (workgroup b runs on XCD b % 8), so that the partial lines of that bin's tile lists are completed in one L2
-    const uint32_t xcd = blockIdx.x % 8, slot = (blockIdx.x / 8) * 4 + wu, slots = (gridDim.x / 8) * 4;
-    const uint32_t q_end = (((total_chunks + 15) / 16 + 7) / 8) * 16;
-    for (uint32_t q = slot; q < q_end; q += slots) {
-        const uint32_t chunk = ((q / 16) * 8 + xcd) * 16 + (q % 16);
-        if (chunk >= total_chunks) continue;
-        uint32_t bin, first, count;
-        bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
-        bin = __builtin_amdgcn_readfirstlane(bin);
-        first = __builtin_amdgcn_readfirstlane(first);
-        count = __builtin_amdgcn_readfirstlane(count);
-        uint64_t m[R];
-        uint32_t g = 0;
-        int lx0 = 0, ly0 = 0, lx1 = 0, ly1 = 0;
-        if ((uint32_t)lane < count) {
-            g = a.cand[first + lane];
-            bin_local_box(a, bin, a.aabb[g], lx0, ly0, lx1, ly1);
-        }
-        bin_cover_masks<R>(a.shift, lx0, ly0, lx1, ly1, m);
-        uint32_t cursor[R];
-        bin_walk<R, false>(m, cursor, __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, 0, 0x27000), nullptr);
-        uint32_t* out = a.chunk_hist + (size_t)chunk * SS;
-#pragma unroll
-        for (int r = 0; r < R; ++r) out[r * 64 + lane] = cursor[r];
-    }
-}
-
-// One block per bin: for each of its tiles, exclusive prefix of the chunk counts (in place) and the tile total.
-__global__ __launch_bounds__(BLOCK) void k_bin_scan(BinArgs a) {
-    __shared__ uint32_t scratch[8];
-    __shared__ uint32_t s_seg[4][64];
-    const int tid = threadIdx.x, S = 1 << a.shift, SS = S * S;
-    const uint32_t bin = blockIdx.x;
-    const uint32_t c = a.bin_count[tid];
-    const uint32_t nch = (c + kBinChunk - 1) / kBinChunk;
-    uint32_t total_chunks;
-    const uint32_t cpre = block_excl_scan<BLOCK>(nch, scratch, &total_chunks);
-    __shared__ uint32_t s_first, s_n;
-    if ((uint32_t)tid == bin) {
-        s_first = cpre;
-        s_n = nch;
-        atomicMax(&a.counters->max_bin, c);  // the fullest bin: the host picks the depth-order path of later frames by it
-    }
+    for (int b = tid; b < NB; b += BLOCK) s_hist[b] = 0;
+    if (tid == 0) s_vis = 0;
     __syncthreads();
-    const uint32_t first = min(s_first, a.max_chunks), n = min(s_n, a.max_chunks - first);
-    const uint32_t ox = (bin % a.bins_x) << a.shift, oy = (bin / a.bins_x) << a.shift;
-    // 64-tile bins: four threads per tile, each sweeping a quarter of the bin's chunks (sum, then prefix);
-    // larger bins: one thread per tile (strided), one sweep
-    const int P = SS == 64 ? 4 : 1;
-    for (int t0 = 0; t0 < SS; t0 += BLOCK / P) {
-        const int t = t0 + (P == 4 ? (tid & 63) : tid);
-        const int seg = P == 4 ? (tid >> 6) : 0;
-        const bool on = t < SS;
-        const uint32_t q0 = (uint32_t)((uint64_t)n * seg / P), q1 = (uint32_t)((uint64_t)n * (seg + 1) / P);
-        uint32_t* base = a.chunk_hist + (size_t)first * SS + (on ? t : 0);
-        uint32_t seg_sum = 0;
-        if (P == 4) {
-            if (on) {
-                uint32_t q = q0;
-                for (; q + 8 <= q1; q += 8) {
-                    uint32_t v[8];
+    uint32_t n = a.n_items ? *a.n_items : a.n_bound;
+    if (n > a.n_bound) n = a.n_bound;
+    uint32_t box[kL1PerWave];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(q + k) * SS];
+    for (int j = 0; j < kL1PerWave; ++j)
+        l1_item(a, blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
+    uint32_t vis = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) seg_sum += v[k];
-                }
-                for (; q < q1; ++q) seg_sum += base[(size_t)q * SS];
-            }
-            s_seg[seg][tid & 63] = seg_sum;
-            __syncthreads();
+    for (int j = 0; j < kL1PerWave; ++j) {
+        uint64_t m[R1];
+        packed_cover_masks<R1>(a.g.grid_shift, box[j], m);
+        vis += (uint32_t)__popcll(__ballot(box[j] != 0));
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+            if (__builtin_amdgcn_ballot_w64(m[r] != 0) == 0) continue;  // uniform: nobody touches these 64 bins
+            const uint32_t pc = (uint32_t)__popcll(wave_transpose64(m[r], lane));
+            if (pc) atomicAdd(&s_hist[r * 64 + lane], pc);
         }
-        uint32_t running = 0;
-        if (P == 4)
-            for (int k = 0; k < seg; ++k) running += s_seg[k][tid & 63];
-        if (on) {
-            uint32_t q = q0;
-            for (; q + 8 <= q1; q += 8) {  // 8 independent loads in flight per step
-                uint32_t v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(q + k) * SS];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    base[(size_t)(q + k) * SS] = running;
-                    running += v[k];
-                }
-            }
-            for (; q < q1; ++q) {
-                const uint32_t v = base[(size_t)q * SS];
-                base[(size_t)q * SS] = running;
-                running += v;
-            }
-            if (seg == P - 1) {
-                const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
-                if (x < a.tiles_x && y < a.tiles_y) a.tile_total[y * a.tiles_x + x] = running;
-            }
-        }
-        if (P == 4) __syncthreads();
     }
+    if (lane == 0 && vis) atomicAdd(&s_vis, vis);
+    __syncthreads();
+    for (int b = tid; b < NB; b += BLOCK)
+        if (bin_on_screen(a.g, b)) a.hist[(size_t)b * a.nblk + blockIdx.x] = s_hist[b];
+    // V on the bin-local path (on the global path the first depth pass counts it)
+    if (tid == 0 && !a.order && s_vis) atomicAdd(&a.counters->visible, s_vis);
 }
 
-// Single block: exclusive scan of the per-tile totals -> ranges (absent tiles stay (0,0) like the
-// reference's zero-filled tileBoundaryBuffer), D -> counters.
-__global__ __launch_bounds__(1024) void k_tile_scan(BinArgs a) {
-    __shared__ uint32_t scratch[16];
-    const uint32_t T = a.tiles_x * a.tiles_y;
+// One workgroup per bin: exclusive prefix of the bin's row of block counts (in place), row total -> bin_count.
+__global__ __launch_bounds__(BLOCK) void k_l1_scan(L1Args a) {
+    __shared__ uint32_t scratch[8];
+    const uint32_t bin = blockIdx.x;
+    if (!bin_on_screen(a.g, bin)) {
+        if (threadIdx.x == 0) a.bin_count[bin] = 0;
+        return;
+    }
+    uint32_t* row = a.hist + (size_t)bin * a.nblk;
     uint32_t running = 0;
-    for (uint32_t base = 0; base < T; base += 4096) {
+    for (uint32_t base = 0; base < a.nblk; base += 4 * BLOCK) {
         const uint32_t i0 = base + threadIdx.x * 4;
         uint32_t v[4], sum = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[k] = i0 + k < T ? a.tile_total[i0 + k] : 0;
+            v[k] = i0 + k < a.nblk ? row[i0 + k] : 0u;
             sum += v[k];
         }
         uint32_t total;
-        uint32_t excl = running + block_excl_scan<1024>(sum, scratch, &total);
+        uint32_t excl = running + block_excl_scan<BLOCK>(sum, scratch, &total);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (i0 + k < T) {
-                // clamped to the list's capacity: an overflowing frame is re-run, but must not read past it
-                a.ranges[2 * (i0 + k)] = v[k] ? min(excl, a.capacity) : 0u;
-                a.ranges[2 * (i0 + k) + 1] = v[k] ? min(excl + v[k], a.capacity) : 0u;
-            }
+            if (i0 + k < a.nblk) row[i0 + k] = excl;
             excl += v[k];
         }
         running += total;
     }
-    if (threadIdx.x == 0) {
-        a.counters->instances = running;
-        if (running > a.capacity) a.counters->overflow |= 1u;
-    }
+    if (threadIdx.x == 0) a.bin_count[bin] = running;
 }
 
-template <int R>
-__global__ __launch_bounds__(BLOCK) void k_bin_fill(BinArgs a) {
-    __shared__ uint32_t s_off[256], s_cpre[256], scratch[8];
-    __shared__ uint32_t s_ids[4][WAVE];
-    const uint32_t total_chunks = min(bin_prepare(a, s_off, s_cpre, scratch), a.max_chunks);
+template <int R1>
+__global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
+    constexpr int NB = 64 * R1;
+    __shared__ uint32_t s_start[NB];            // where this block's run starts in each bin's list
+    __shared__ uint16_t s_cnt[kL1Chunks][NB];   // per chunk and bin: count, then exclusive prefix over the chunks
+    __shared__ uint32_t s_ids[kL1Chunks][WAVE];
+    __shared__ uint32_t scratch[8];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    constexpr int SS = 64 * R;
-    const int S = 1 << a.shift;
-    // raw buffer over the list: byte offsets >= 4 * capacity are dropped by the hardware bounds check
-    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, a.capacity * 4u, 0x27000);
-    // the chunk loop is per wave: tell the compiler its control values are wave-uniform (scalar registers)
-    const uint32_t wu = __builtin_amdgcn_readfirstlane((uint32_t)w);
-    // chunk -> wave: groups of 16 consecutive chunks (1024 candidates, nearly always one bin) stay on one XCD
-    // (workgroup b runs on XCD b % 8), so that the partial lines of that bin's tile lists are completed in one L2
-    const uint32_t xcd = blockIdx.x % 8, slot = (blockIdx.x / 8) * 4 + wu, slots = (gridDim.x / 8) * 4;
-    const uint32_t q_end = (((total_chunks + 15) / 16 + 7) / 8) * 16;
-    for (uint32_t q = slot; q < q_end; q += slots) {
-        const uint32_t chunk = ((q / 16) * 8 + xcd) * 16 + (q % 16);
-        if (chunk >= total_chunks) continue;
-        uint32_t bin, first, count;
-        bin_locate(a, s_off, s_cpre, chunk, bin, first, count);
-        bin = __builtin_amdgcn_readfirstlane(bin);
-        first = __builtin_amdgcn_readfirstlane(first);
-        count = __builtin_amdgcn_readfirstlane(count);
-        uint64_t m[R];
-        uint32_t g = 0;
-        int lx0 = 0, ly0 = 0, lx1 = 0, ly1 = 0;
-        if ((uint32_t)lane < count) {
-            g = a.cand[first + lane];
-            bin_local_box(a, bin, a.aabb[g], lx0, ly0, lx1, ly1);
-        }
-        bin_cover_masks<R>(a.shift, lx0, ly0, lx1, ly1, m);
-        // where this chunk's run starts in each tile's list: range start + earlier chunks of the bin
-        const uint32_t ox = (bin % a.bins_x) << a.shift, oy = (bin / a.bins_x) << a.shift;
-        const uint32_t* prefix = a.chunk_hist + (size_t)chunk * SS;
-        uint32_t cursor[R];
+    {   // bin offsets = exclusive scan of the bin totals (<= 1024 values: every block redoes it, no extra launch)
+        uint32_t c[NB / BLOCK], sum = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int t = r * 64 + lane;
-            const uint32_t x = ox + (t & (S - 1)), y = oy + (t >> a.shift);
-            cursor[r] = (x < a.tiles_x && y < a.tiles_y) ? a.ranges[2 * (y * a.tiles_x + x)] + prefix[t] : 0u;
+        for (int k = 0; k < NB / BLOCK; ++k) {
+            c[k] = a.bin_count[tid * (NB / BLOCK) + k];
+            sum += c[k];
         }
-        s_ids[w][lane] = g;
-        bin_walk<R, true>(m, cursor, out, s_ids[w]);  // append, in candidate order
+        uint32_t total;
+        uint32_t off = block_excl_scan<BLOCK>(sum, scratch, &total);
+#pragma unroll
+        for (int k = 0; k < NB / BLOCK; ++k) {
+            const uint32_t b = tid * (NB / BLOCK) + k;
+            s_start[b] = off + (bin_on_screen(a.g, b) ? a.hist[(size_t)b * a.nblk + blockIdx.x] : 0u);
+            off += c[k];
+            if (blockIdx.x == 0 && c[k]) atomicMax(&a.counters->max_bin, c[k]);  // the fullest bin
+        }
+        if (blockIdx.x == 0 && tid == 0) {  // E1, candidate overflow
+            a.counters->bin_entries = total;
+            if (total > a.capacity) atomicOr(&a.counters->overflow, 1u);
+        }
+    }
+    uint32_t n = a.n_items ? *a.n_items : a.n_bound;
+    if (n > a.n_bound) n = a.n_bound;
+    uint32_t box[kL1PerWave];
+#pragma unroll
+    for (int j = 0; j < kL1PerWave; ++j) {
+        const int ch = w * kL1PerWave + j;
+        s_ids[ch][lane] = l1_item(a, blockIdx.x * kL1Items + ch * WAVE + lane, n, box[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kL1PerWave; ++j) {
+        const int ch = w * kL1PerWave + j;
+        uint64_t m[R1];
+        packed_cover_masks<R1>(a.g.grid_shift, box[j], m);
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+            const uint64_t col = __builtin_amdgcn_ballot_w64(m[r] != 0) != 0 ? wave_transpose64(m[r], lane) : 0ull;
+            s_cnt[ch][r * 64 + lane] = (uint16_t)__popcll(col);
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < NB; b += BLOCK) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < kL1Chunks; ++k) {
+            const uint32_t v = s_cnt[k][b];
+            s_cnt[k][b] = (uint16_t)run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    // raw buffer over the candidate list: byte offsets >= 4 * capacity are dropped by the hardware bounds check
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.cand, 0, a.capacity * 4u, 0x27000);
+#pragma unroll
+    for (int j = 0; j < kL1PerWave; ++j) {
+        const int ch = w * kL1PerWave + j;
+        uint64_t m[R1];
+        packed_cover_masks<R1>(a.g.grid_shift, box[j], m);
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+            if (__builtin_amdgcn_ballot_w64(m[r] != 0) == 0) continue;
+            walk_column(wave_transpose64(m[r], lane), s_start[r * 64 + lane] + s_cnt[ch][r * 64 + lane], out, s_ids[ch]);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// Depth order INSIDE the bins (the bin-local path).  The candidates of a bin arrive in Gaussian-index order (stable
-// radix pass by bin over candidates emitted in index order); one workgroup per bin orders them by (depth bits, id)
-// entirely in LDS: four stable 8-bit LSD passes over (key, id) pairs, no global traffic and no kernel boundary
-// between the passes.  This replaces the twelve kernels of the global depth order.
-// A bin with more than kBinSortMax candidates does not fit: the kernel raises overflow bit 2 and the host re-runs
-// the frame on the global-depth-order path.
-//
-// (wave, round, lane) order is list order; the stable rank inside (wave, digit) comes from wave64 ballot matching as
-// in k_radix_scatter.
+// Level 2.  One workgroup per bin.
+//   SORT: the bin's candidates arrive in Gaussian-index order and are put into (depth bits, id) order entirely in
+//   LDS: four stable 8-bit LSD passes over (key, id) pairs, sorted in place because between the ranking and the
+//   scatter of a pass every element lives in registers.  (wave, round, lane) order is list order; the stable rank
+//   inside (wave, digit) comes from wave64 ballot matching.  Two sizes: 256 threads order up to 4096 candidates
+//   (40 KiB of LDS: four workgroups per CU, every bin of a 1080p frame resident at once), 1024 threads up to 16384.
+//   A bin beyond the size in use raises overflow bit 2 and the host re-runs the frame with the next size, and
+//   beyond 16384 on the global depth-order path.
+//   !SORT: the candidates already are in depth order (global path) and are streamed from memory, any number.
 // ---------------------------------------------------------------------------------------
-constexpr int kBinSortThreads = 1024;
-__global__ __launch_bounds__(kBinSortThreads) void k_bin_sort(const uint32_t* __restrict__ bin_count,
-                                                              const uint32_t* __restrict__ ids_in,
-                                                              const float* __restrict__ depth,
-                                                              uint32_t* __restrict__ ids_out, Counters* counters) {
-    // ONE (key, id) buffer: between the ranking and the scatter of a pass every element lives in registers (two
-    // barriers apart), so a pass scatters back into the buffer it read -- 16 384 entries in 128 KiB
-    __shared__ uint32_t s_key[kBinSortMax];
-    __shared__ uint32_t s_id[kBinSortMax];
-    __shared__ uint32_t s_wcnt[16][256];  // per-wave digit counters, then per-wave write cursors
-    __shared__ uint32_t scratch[16];
+struct BuildArgs {
+    BinGrid g;
+    const uint32_t* cand;
+    const uint32_t* bin_count;
+    const float* depth;
+    const ushort4* aabb;
+    uint32_t* ranges;      // [T][2]
+    uint32_t* sorted_gid;  // [capacity]
+    Counters* counters;
+    uint32_t capacity;
+};
+
+// candidate's tile box clipped to the bin, in bin-local tile coordinates (upper bounds exclusive), packed like l1_item's
+__device__ __forceinline__ uint32_t bin_local_box(const BinGrid& g, uint32_t bin, ushort4 box) {
+    const int S = 1 << g.bin_shift;
+    const int ox = (int)(bin & ((1u << g.grid_shift) - 1u)) << g.bin_shift, oy = (int)(bin >> g.grid_shift) << g.bin_shift;
+    const int lx0 = max((int)box.x, ox) - ox, ly0 = max((int)box.y, oy) - oy;
+    const int lx1 = min((int)box.z, ox + S) - ox, ly1 = min((int)box.w, oy + S) - oy;
+    return (uint32_t)lx0 | ((uint32_t)ly0 << 8) | ((uint32_t)lx1 << 16) | ((uint32_t)ly1 << 24);
+}
+
+constexpr int kBuildSlots = 16;  // chunks per fill round (one or four per wave)
+
+template <int R2, int THREADS, bool SORT>
+struct BuildLayout {
+    static constexpr int NW = THREADS / WAVE;
+    static constexpr int MAXC = SORT ? THREADS * 16 : 0;   // 4096 or 16384 candidates in LDS
+    static constexpr int SS = 64 * R2;                     // tile slots of a bin (S = 4: 16 of the 64 are real)
+    static constexpr bool CACHE_BOX = SORT && R2 <= 4;     // bin-local boxes kept in the key area once the order is final
+    static constexpr int TABLES = 3 * SS + kBuildSlots * SS / 2 + (SORT ? 0 : kBuildSlots * WAVE);  // u32 words
+    static constexpr int WCNT = SORT ? NW * 256 : 0;
+    // [keys / boxes MAXC][ids MAXC][wcnt]; once the order is final the tables go behind the ids (over wcnt), or into
+    // the key area when that is free (boxes not cached) and large enough
+    static constexpr int T_OFF = (SORT && (CACHE_BOX || TABLES > MAXC)) ? 2 * MAXC : 0;
+    static constexpr int WORDS = (T_OFF + TABLES > 2 * MAXC + WCNT) ? T_OFF + TABLES : 2 * MAXC + WCNT;
+};
+
+template <int R2, int THREADS, bool SORT>
+__global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
+    using L = BuildLayout<R2, THREADS, SORT>;
+    constexpr int NW = L::NW, MAXC = L::MAXC, SS = L::SS, PER = kBuildSlots / NW;  // PER chunks per wave and round
+    extern __shared__ uint32_t smem[];
+    uint32_t* const s_key = smem;            // SORT; later the packed bin-local boxes (CACHE_BOX)
+    uint32_t* const s_id = smem + MAXC;      // SORT
+    uint32_t (*const s_wcnt)[256] = reinterpret_cast<uint32_t(*)[256]>(smem + 2 * MAXC);
+    uint32_t* const t_cnt = smem + L::T_OFF;                                               // [SS] instances per tile
+    uint32_t* const t_cur = t_cnt + SS;                                                    // [2][SS] list cursors (ping-pong)
+    uint16_t (*const r_cnt)[SS] = reinterpret_cast<uint16_t(*)[SS]>(t_cnt + 3 * SS);      // [16][SS] per round
+    uint32_t* const w_ids = t_cnt + 3 * SS + kBuildSlots * SS / 2;                         // [16][64] (!SORT)
+    __shared__ uint32_t scratch[NW];
+    __shared__ uint32_t s_seg;
+
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const uint32_t bin = blockIdx.x;
+    if (!bin_on_screen(a.g, bin)) return;  // padding of the bin grid: no tiles
     uint32_t c, off;
-    {
-        const uint32_t v = tid < 256 ? bin_count[tid] : 0u;
-        uint32_t all;
-        const uint32_t excl = block_excl_scan<kBinSortThreads>(v, scratch, &all);
-        __shared__ uint32_t s_c, s_o;
-        if ((uint32_t)tid == bin) {
-            s_c = v;
-            s_o = excl;
+    {   // this bin's count and offset (exclusive scan over the <= 1024 bins of the padded grid)
+        const uint32_t nb = 1u << (2 * a.g.grid_shift);
+        uint32_t mine = 0, before = 0;
+        for (uint32_t b = tid; b < nb; b += THREADS) {
+            const uint32_t v = a.bin_count[b];
+            if (b < bin) before += v;
+            if (b == bin) mine = v;
         }
-        __syncthreads();
-        c = s_c;
-        off = s_o;
+        uint32_t tot_before, tot_mine;
+        block_excl_scan<THREADS>(before, scratch, &tot_before);
+        block_excl_scan<THREADS>(mine, scratch, &tot_mine);
+        c = tot_mine;
+        off = tot_before;
     }
-    if (c == 0) return;
-    if (c > (uint32_t)kBinSortMax) {
-        if (tid == 0) atomicOr(&counters->overflow, 2u);
-        return;
+    if ((uint64_t)off + c > a.capacity) c = 0;  // candidate overflow (flagged by k_l1_scatter): the frame is re-run
+    if (SORT && c > (uint32_t)MAXC) {
+        if (tid == 0) atomicOr(&a.counters->overflow, 2u);
+        c = 0;
     }
-    for (uint32_t e = tid; e < c; e += kBinSortThreads) {
-        const uint32_t g = ids_in[off + e];
-        s_id[e] = g;
-        s_key[e] = __float_as_uint(depth[g]);
-    }
-    constexpr int kRounds = kBinSortMax / kBinSortThreads;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64: all 16 waves share the work
-    const int rounds = (int)((c + kBinSortThreads - 1) / kBinSortThreads);  // block-uniform, <= kRounds
-    const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
+    if (SORT && c != 0) {
+        for (uint32_t e = tid; e < c; e += THREADS) {
+            const uint32_t g = a.cand[off + e];
+            s_id[e] = g;
+            s_key[e] = __float_as_uint(a.depth[g]);
+        }
+        constexpr int kRounds = 16;  // MAXC / THREADS
+        const uint64_t lt_mask = (1ull << lane) - 1ull;
+        // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
+        const int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= kRounds
+        const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = pass * 8;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = pass * 8;
+            for (int k = tid; k < NW * 256; k += THREADS) s_wcnt[k >> 8][k & 255] = 0;
+            __syncthreads();  // also orders the previous pass's (or the load's) LDS writes before this pass's reads
+            uint32_t key[kRounds], id[kRounds], rank[kRounds];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_wcnt[(tid >> 8) * 4 + k][tid & 255] = 0;
-        __syncthreads();  // also orders the previous pass's (or the load's) LDS writes before this pass's reads
-        uint32_t key[kRounds], id[kRounds], rank[kRounds];
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-            key[r] = 0;
-            id[r] = 0;
-            rank[r] = 0;
-            if (r < rounds) {
-                const uint32_t e = wbase + r * WAVE + lane;
-                const bool ok = e < c;
-                if (ok) {
-                    key[r] = s_key[e];
-                    id[r] = s_id[e];
-                }
-                const uint32_t d = (key[r] >> shift) & 255u;
-                // lanes holding a valid key with my digit: AND over the bits of (ballot(bit) XNOR my bit), in 32-bit halves
-                const uint64_t okm = __ballot(ok);
-                uint32_t mlo = (uint32_t)okm, mhi = (uint32_t)(okm >> 32);
-#pragma unroll
-                for (int bit = 0; bit < 8; ++bit) {
-                    const uint32_t mine = (d >> bit) & 1u;
-                    const uint64_t b = __builtin_amdgcn_ballot_w64(mine != 0);
-                    const uint32_t splat = 0u - mine;
-                    mlo &= ~((uint32_t)b ^ splat);
-                    mhi &= ~((uint32_t)(b >> 32) ^ splat);
-                }
-                const uint64_t m = ((uint64_t)mhi << 32) | mlo;
-                uint32_t old = 0;
-                const int leader = m ? (__ffsll((unsigned long long)m) - 1) : 0;
-                if (ok && lane == leader) {
-                    old = s_wcnt[w][d];
-                    s_wcnt[w][d] = old + (uint32_t)__popcll(m);
-                }
-                old = __shfl(old, leader, WAVE);
-                rank[r] = old + (uint32_t)__popcll(m & lt_mask);
-            }
-        }
-        __syncthreads();
-        {   // per digit: prefix over the 16 waves, then exclusive scan over the digits -> per-wave write cursors
-            uint32_t cw[16], cnt = 0;
-            if (tid < 256) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    cw[k] = s_wcnt[k][tid];
-                    cnt += cw[k];
-                }
-            }
-            uint32_t all;
-            uint32_t excl = block_excl_scan<kBinSortThreads>(cnt, scratch, &all);
-            if (tid < 256) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    s_wcnt[k][tid] = excl;
-                    excl += cw[k];
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-            if (r < rounds) {
-                const uint32_t e = wbase + r * WAVE + lane;
-                if (e < c) {
+            for (int r = 0; r < kRounds; ++r) {
+                key[r] = 0;
+                id[r] = 0;
+                rank[r] = 0;
+                if (r < rounds) {
+                    const uint32_t e = wbase + r * WAVE + lane;
+                    const bool ok = e < c;
+                    if (ok) {
+                        key[r] = s_key[e];
+                        id[r] = s_id[e];
+                    }
                     const uint32_t d = (key[r] >> shift) & 255u;
-                    const uint32_t pos = s_wcnt[w][d] + rank[r];
-                    s_key[pos] = key[r];
-                    s_id[pos] = id[r];
+                    // lanes holding a valid key with my digit: AND over the bits of (ballot(bit) XNOR my bit)
+                    const uint64_t okm = __ballot(ok);
+                    uint32_t mlo = (uint32_t)okm, mhi = (uint32_t)(okm >> 32);
+#pragma unroll
+                    for (int bit = 0; bit < 8; ++bit) {
+                        const uint32_t mine = (d >> bit) & 1u;
+                        const uint64_t b = __builtin_amdgcn_ballot_w64(mine != 0);
+                        const uint32_t splat = 0u - mine;
+                        mlo &= ~((uint32_t)b ^ splat);
+                        mhi &= ~((uint32_t)(b >> 32) ^ splat);
+                    }
+                    const uint64_t m = ((uint64_t)mhi << 32) | mlo;
+                    uint32_t old = 0;
+                    const int leader = m ? (__ffsll((unsigned long long)m) - 1) : 0;
+                    if (ok && lane == leader) {
+                        old = s_wcnt[w][d];
+                        s_wcnt[w][d] = old + (uint32_t)__popcll(m);
+                    }
+                    old = __shfl(old, leader, WAVE);
+                    rank[r] = old + (uint32_t)__popcll(m & lt_mask);
                 }
             }
+            __syncthreads();
+            {   // per digit: prefix over the waves, then exclusive scan over the digits -> per-wave write cursors
+                uint32_t cw[NW], cnt = 0;
+                if (tid < 256) {
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) {
+                        cw[k] = s_wcnt[k][tid];
+                        cnt += cw[k];
+                    }
+                }
+                uint32_t all;
+                uint32_t excl = block_excl_scan<THREADS>(cnt, scratch, &all);
+                if (tid < 256) {
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) {
+                        s_wcnt[k][tid] = excl;
+                        excl += cw[k];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                if (r < rounds) {
+                    const uint32_t e = wbase + r * WAVE + lane;
+                    if (e < c) {
+                        const uint32_t d = (key[r] >> shift) & 255u;
+                        const uint32_t pos = s_wcnt[w][d] + rank[r];
+                        s_key[pos] = key[r];
+                        s_id[pos] = id[r];
+                    }
+                }
+            }
+            __syncthreads();  // the cursors in s_wcnt are re-zeroed at the top of the next pass
         }
-        __syncthreads();  // the cursors in s_wcnt are re-zeroed at the top of the next pass
+        if (L::CACHE_BOX) {  // the order is final: the key area now holds every candidate's bin-local tile box
+            for (uint32_t e = tid; e < c; e += THREADS) s_key[e] = bin_local_box(a.g, bin, a.aabb[s_id[e]]);
+        }
     }
-    for (uint32_t e = tid; e < c; e += kBinSortThreads) ids_out[off + e] = s_id[e];
+    // ---- per-tile counts (the tables live behind the ids, or in the key area when the boxes are not cached)
+    for (int t = tid; t < SS; t += THREADS) t_cnt[t] = 0;
+    __syncthreads();
+    const uint32_t nch = (c + WAVE - 1) / WAVE;
+    // chunk ch of the bin's list -> this lane's candidate and the columns of the bin's tiles
+    auto chunk_columns = [&](uint32_t ch, uint64_t (&col)[R2], uint32_t& gid) {
+        const uint32_t e = ch * WAVE + lane;
+        uint32_t box = 0;
+        gid = 0;
+        if (e < c) {
+            gid = SORT ? s_id[e] : a.cand[off + e];
+            box = L::CACHE_BOX ? s_key[e] : bin_local_box(a.g, bin, a.aabb[gid]);
+        }
+        packed_cover_masks<R2>(a.g.bin_shift, box, col);
+#pragma unroll
+        for (int r = 0; r < R2; ++r)
+            col[r] = (R2 == 1 || __builtin_amdgcn_ballot_w64(col[r] != 0) != 0) ? wave_transpose64(col[r], lane) : 0ull;
+    };
+    {
+        uint32_t acc[R2];
+#pragma unroll
+        for (int r = 0; r < R2; ++r) acc[r] = 0;
+        for (uint32_t ch = w; ch < nch; ch += NW) {
+            uint64_t col[R2];
+            uint32_t gid;
+            chunk_columns(ch, col, gid);
+#pragma unroll
+            for (int r = 0; r < R2; ++r) acc[r] += (uint32_t)__popcll(col[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R2; ++r)
+            if (acc[r]) atomicAdd(&t_cnt[r * 64 + lane], acc[r]);
+    }
+    __syncthreads();
+    // ---- tile ranges: a segment of the list buffer for the bin (tiles consecutive inside it)
+    {
+        uint32_t v[(SS + THREADS - 1) / THREADS], sum = 0;
+#pragma unroll
+        for (int k = 0; k < (SS + THREADS - 1) / THREADS; ++k) {  // thread t owns tiles t * K .. t * K + K - 1
+            const int t = tid * ((SS + THREADS - 1) / THREADS) + k;
+            v[k] = t < SS ? t_cnt[t] : 0u;
+            sum += v[k];
+        }
+        uint32_t d_bin;
+        uint32_t excl = block_excl_scan<THREADS>(sum, scratch, &d_bin);
+        if (tid == 0) {
+            const uint32_t seg = d_bin ? atomicAdd(&a.counters->instances, d_bin) : 0u;
+            s_seg = seg;
+            if ((uint64_t)seg + d_bin > a.capacity) atomicOr(&a.counters->overflow, 1u);
+        }
+        __syncthreads();
+        const uint32_t S = 1u << a.g.bin_shift;
+        const uint32_t ox = (bin & ((1u << a.g.grid_shift) - 1u)) << a.g.bin_shift, oy = (bin >> a.g.grid_shift) << a.g.bin_shift;
+#pragma unroll
+        for (int k = 0; k < (SS + THREADS - 1) / THREADS; ++k) {
+            const int t = tid * ((SS + THREADS - 1) / THREADS) + k;
+            if (t < SS) {
+                const uint32_t lx = (uint32_t)t & (S - 1), ly = (uint32_t)t >> a.g.bin_shift;
+                const uint32_t x = ox + lx, y = oy + ly;
+                // saturating: an overflowing frame is re-run, but its ranges must stay inside the list
+                const uint64_t start64 = (uint64_t)s_seg + excl;
+                const uint32_t start = start64 > a.capacity ? a.capacity : (uint32_t)start64;
+                const uint32_t end = start64 + v[k] > a.capacity ? a.capacity : (uint32_t)(start64 + v[k]);
+                if (ly < S && x < a.g.tiles_x && y < a.g.tiles_y) {
+                    // absent tiles stay (0, 0) like the reference's zero-filled tileBoundaryBuffer
+                    a.ranges[2 * (y * a.g.tiles_x + x)] = v[k] ? start : 0u;
+                    a.ranges[2 * (y * a.g.tiles_x + x) + 1] = v[k] ? end : 0u;
+                }
+                t_cur[t] = start;
+            }
+            excl += v[k];
+        }
+    }
+    __syncthreads();
+    // ---- fill, 16 chunks per round (PER per wave, consecutive) so that the lists keep the candidates' order
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, a.capacity * 4u, 0x27000);
+    int par = 0;
+    for (uint32_t rb = 0; rb < nch; rb += kBuildSlots, par ^= 1) {
+        uint64_t col[PER][R2];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int slot = w * PER + j;
+            uint32_t gid;
+            chunk_columns(rb + slot, col[j], gid);  // chunks past the end have empty columns
+#pragma unroll
+            for (int r = 0; r < R2; ++r) r_cnt[slot][r * 64 + lane] = (uint16_t)__popcll(col[j][r]);
+            if (!SORT) w_ids[slot * WAVE + lane] = gid;
+        }
+        __syncthreads();
+        for (int t = tid; t < SS; t += THREADS) {  // per tile: where each slot's run starts, and the next round's cursor
+            uint32_t run = 0;
+#pragma unroll
+            for (int k = 0; k < kBuildSlots; ++k) {
+                const uint32_t v = r_cnt[k][t];
+                r_cnt[k][t] = (uint16_t)run;
+                run += v;
+            }
+            t_cur[(par ^ 1) * SS + t] = t_cur[par * SS + t] + run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int slot = w * PER + j;
+            const uint32_t ch = rb + slot;
+            const uint32_t* ids = SORT ? s_id + (ch < nch ? ch : 0u) * WAVE : w_ids + slot * WAVE;
+#pragma unroll
+            for (int r = 0; r < R2; ++r) {
+                if (__builtin_amdgcn_ballot_w64(col[j][r] != 0) == 0) continue;
+                walk_column(col[j][r], t_cur[par * SS + r * 64 + lane] + r_cnt[slot][r * 64 + lane], out, ids);
+            }
+        }
+    }
 }
 
-void launch_bin_sort(const uint32_t* bin_count, const uint32_t* ids_in, const float* depth, uint32_t* ids_out,
-                     Counters* counters, uint32_t bins, hipStream_t s) {
-    hipLaunchKernelGGL(k_bin_sort, dim3(bins), dim3(kBinSortThreads), 0, s, bin_count, ids_in, depth, ids_out, counters);
+static L1Args l1_args(const BinLaunch& b) {
+    L1Args a;
+    a.g = BinGrid{b.tiles_x, b.tiles_y, b.bins_x, b.bins_y, b.bin_shift, b.grid_shift};
+    a.order = b.order;
+    a.n_items = b.n_items;
+    a.n_bound = b.n_bound;
+    a.tiles = b.tiles;
+    a.aabb = b.aabb;
+    a.hist = b.hist;
+    a.bin_count = b.bin_count;
+    a.cand = b.cand;
+    a.counters = b.counters;
+    a.capacity = b.capacity;
+    a.nblk = bin_level1_blocks(b.n_bound);
+    return a;
 }
 
-static BinArgs bin_args(const BinLaunch& b) {
-    BinArgs a;
+uint32_t bin_level1_blocks(uint32_t n_items) { return (n_items + kL1Items - 1) / kL1Items; }
+
+void launch_bin_level1_count(const BinLaunch& b, hipStream_t s) {
+    const L1Args a = l1_args(b);
+    if (a.nblk == 0) return;
+    if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_hist<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(k_l1_hist<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_l1_scan, dim3(1u << (2 * b.grid_shift)), dim3(BLOCK), 0, s, a);
+}
+
+void launch_bin_level1_scatter(const BinLaunch& b, hipStream_t s) {
+    const L1Args a = l1_args(b);
+    if (a.nblk == 0) return;
+    if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_scatter<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(k_l1_scatter<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+}
+
+template <int R2, int THREADS, bool SORT>
+static hipError_t build_prepare() {  // > 64 KiB of dynamic LDS needs the attribute
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_build<R2, THREADS, SORT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(BuildLayout<R2, THREADS, SORT>::WORDS * sizeof(uint32_t)));
+}
+hipError_t bin_prepare_device() {  // once per device (gs_renderer::init)
+    hipError_t e = build_prepare<1, 1024, true>();
+    if (e == hipSuccess) e = build_prepare<4, 1024, true>();
+    if (e == hipSuccess) e = build_prepare<16, 1024, true>();
+    if (e == hipSuccess) e = build_prepare<16, 256, true>();
+    return e;
+}
+
+template <int R2>
+static void launch_build(const BuildArgs& a, int variant, uint32_t bins, hipStream_t s) {
+    constexpr size_t lds0 = BuildLayout<R2, 256, true>::WORDS * sizeof(uint32_t);
+    constexpr size_t lds1 = BuildLayout<R2, 1024, true>::WORDS * sizeof(uint32_t);
+    constexpr size_t lds2 = BuildLayout<R2, 1024, false>::WORDS * sizeof(uint32_t);
+    if (variant == 0) hipLaunchKernelGGL((k_bin_build<R2, 256, true>), dim3(bins), dim3(256), lds0, s, a);
+    else if (variant == 1) hipLaunchKernelGGL((k_bin_build<R2, 1024, true>), dim3(bins), dim3(1024), lds1, s, a);
+    else hipLaunchKernelGGL((k_bin_build<R2, 1024, false>), dim3(bins), dim3(1024), lds2, s, a);
+}
+
+void launch_bin_level2(const BinLaunch& b, int variant, hipStream_t s) {
+    BuildArgs a;
+    a.g = BinGrid{b.tiles_x, b.tiles_y, b.bins_x, b.bins_y, b.bin_shift, b.grid_shift};
     a.cand = b.cand;
     a.bin_count = b.bin_count;
+    a.depth = b.depth;
     a.aabb = b.aabb;
-    a.chunk_hist = b.chunk_hist;
-    a.tile_total = b.tile_total;
     a.ranges = b.ranges;
     a.sorted_gid = b.sorted_gid;
     a.counters = b.counters;
     a.capacity = b.capacity;
-    a.tiles_x = b.tiles_x;
-    a.tiles_y = b.tiles_y;
-    a.bins_x = b.bins_x;
-    a.shift = b.shift;
-    a.max_chunks = b.max_chunks;
-    return a;
-}
-
-void launch_bin_ranges(const BinLaunch& b, hipStream_t s) {
-    const BinArgs a = bin_args(b);
-    if (b.shift == 3) hipLaunchKernelGGL(k_bin_count<1>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
-    else if (b.shift == 4) hipLaunchKernelGGL(k_bin_count<4>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
-    else hipLaunchKernelGGL(k_bin_count<16>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
-    hipLaunchKernelGGL(k_bin_scan, dim3(b.bins), dim3(BLOCK), 0, s, a);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, a);
-}
-
-void launch_bin_fill(const BinLaunch& b, hipStream_t s) {
-    const BinArgs a = bin_args(b);
-    if (b.shift == 3) hipLaunchKernelGGL(k_bin_fill<1>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
-    else if (b.shift == 4) hipLaunchKernelGGL(k_bin_fill<4>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
-    else hipLaunchKernelGGL(k_bin_fill<16>, dim3(kBinGrid), dim3(BLOCK), 0, s, a);
+    const uint32_t bins = 1u << (2 * b.grid_shift);
+    if (b.bin_shift <= 3) launch_build<1>(a, variant, bins, s);
+    else if (b.bin_shift == 4) launch_build<4>(a, variant, bins, s);
+    else launch_build<16>(a, variant, bins, s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1374,6 +1348,7 @@ __device__ __forceinline__ void blend_fetch(BlendEntry& e, uint32_t g, const flo
     e.b = bch[g];
 }
 
+template <bool HW_EXP>
 __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ sorted_gid,
                                                  const uint32_t* __restrict__ tile_order,
@@ -1450,7 +1425,10 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
             STAT_ADD(6, __popcll(__ballot(have)));
             STAT_ADD(1, __popcll(bm));
             if (bm == 0) continue;
-            s_rec[w][0][lane] = cur.co;
+            // conic pre-scaled once per entry: (-c00/2, -c01, -c11/2).  Scaling by a power of two commutes with every
+            // rounding below, so power is bit-identical to render.comp:66 evaluated as written (with its three
+            // contractions) while the per-pixel body loses the -0.5 multiply
+            s_rec[w][0][lane] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
             s_rec[w][1][lane] = cur.uv;
             s_rec[w][2][lane] = make_float4(cur.b, -lim, 0.0f, 0.0f);
 
@@ -1468,25 +1446,28 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                 const float dx = uv.x - fx;
                 const float dy = uv.y - fy;
                 // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
-                const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);        // FMA
-                const float power = __builtin_fmaf(-(co.y * dx), dy, -0.5f * s);      // FMA
+                const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);        // FMA  (= -0.5 * the shader's sum)
+                const float power = __builtin_fmaf(co.y * dx, dy, s);                 // FMA
                 // power <= 0 is false for NaN: a NaN power skips the entry (the pipeline's definition)
                 const uint64_t m1 = alive & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                     __builtin_amdgcn_ballot_w64(!(power < bp.y));
                 if (m1 != 0) {
                     STAT_ADD(4, 1);                   // pairs reaching exp
                     STAT_ADD(5, __popcll(m1));        // lanes needing exp
-                    const float alpha = fminf(0.99f, co.w * gs_exp_blend(power));  // :77
+                    // :77.  HW_EXP: the hardware's v_exp_f32 (what a Vulkan driver emits for exp()); otherwise the
+                    // pipeline-defined polynomial that the oracle reproduces bit for bit
+                    const float ex = HW_EXP ? __builtin_amdgcn_exp2f(power * 1.44269502162933349609375f) : gs_exp_blend(power);
+                    const float alpha = fminf(0.99f, co.w * ex);
                     const uint64_t m2 = m1 & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
                     const float test_T = T * (1 - alpha);
                     const uint64_t mk = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);  // :82-85 break
                     const bool upd = __builtin_amdgcn_inverse_ballot_w64(m2 & ~mk);
-                    // lanes that do not take this entry add rgb * 0 * T: exactly nothing
-                    const float a_eff = upd ? alpha : 0.0f;
-                    c0 = __builtin_fmaf(uv.z * a_eff, T, c0);  // :87  FMA
-                    c1 = __builtin_fmaf(uv.w * a_eff, T, c1);
-                    c2 = __builtin_fmaf(bp.x * a_eff, T, c2);
-                    T = upd ? test_T : T;
+                    if (upd) {  // the accumulate runs under the exec mask: no selects
+                        c0 = __builtin_fmaf(uv.z * alpha, T, c0);  // :87  FMA
+                        c1 = __builtin_fmaf(uv.w * alpha, T, c1);
+                        c2 = __builtin_fmaf(bp.x * alpha, T, c2);
+                        T = test_T;
+                    }
                     alive &= ~mk;
                     if (alive == 0) bm = 0;
                 }
@@ -1511,12 +1492,17 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
-                  Counters* host_counters, hipStream_t s) {
+                  Counters* host_counters, bool hw_exp, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_blend, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
-                       sorted_gid, tile_order, av.conic_op, av.uv_rg, av.b, width, height, tx,
-                       reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters);
+    if (hw_exp)
+        hipLaunchKernelGGL(k_blend<true>, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
+                           sorted_gid, tile_order, av.conic_op, av.uv_rg, av.b, width, height, tx,
+                           reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters);
+    else
+        hipLaunchKernelGGL(k_blend<false>, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
+                           sorted_gid, tile_order, av.conic_op, av.uv_rg, av.b, width, height, tx,
+                           reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters);
 }
 
 #ifdef GS_BLEND_STATS

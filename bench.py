@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one frame: preprocess -> depth order -> scan -> duplicate -> tile sort -> tile ranges ->
-blend, over the synthetic scene S(1e6) at 1920x1080 (BASELINE configs[1]); the scene is resident in
+A "step" is one frame: preprocess -> level-1 binning (count, scan, scatter) -> per-bin depth order + tile
+lists -> blend, over the synthetic scene S(1e6) at 1920x1080 (BASELINE configs[1]); the scene is resident in
 HBM before the timed region and the RGBA32F frame stays in HBM.  With N > 1 the scene blob is
 broadcast once over RCCL/xGMI and every rank renders its own camera pose (configs[3]): no per-frame
 collective, weak scaling, value = N*K frames / max-over-ranks time.
@@ -50,27 +50,34 @@ def workload_name(n, w, h, world):
     return base + " (not a BASELINE config)"
 
 
-def algorithmic_bytes(n, v, d, e1, t, p, bin_local=True):
-    """Implementation-independent HBM bytes per frame and pass for this decomposition.
-    n Gaussians, v visible, d tile instances, e1 (bin, Gaussian) candidates, t tiles, p pixels.
-    bin_local: the depth order is taken inside the bins (k_bin_sort) instead of by four global passes over V."""
-    if bin_local:
-        pre_extra, scan_items, dup_items = 4 * n, n, n            # bins-per-Gaussian plane out; scan / emit over all N
-        order = (4 + 4 + 4) * e1                                  # k_bin_sort: id in, depth gathered, id out
-    else:
-        pre_extra, scan_items, dup_items = 0, v, v
-        order = 4 * (4 + 16) * v                                  # 4 passes over V: histogram read 4 + (key, id) in 8 + out 8
+def bin_grid(w, h, min_shift=2):
+    """The bin grid gs_renderer::bin_geometry picks: bins of S x S tiles, S the smallest power of two >= 4 that keeps
+    the grid within 32 x 32.  Returns (S, bins)."""
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    s = min_shift
+    while ((tx - 1) >> s) + 1 > 32 or ((ty - 1) >> s) + 1 > 32:
+        s += 1
+    return 1 << s, (((tx - 1) >> s) + 1) * (((ty - 1) >> s) + 1)
+
+
+def algorithmic_bytes(n, v, d, e1, t, p, bins, bin_local=True):
+    """HBM bytes per frame and pass that THIS decomposition has to move, whatever the kernels do
+    internally.  n Gaussians, v visible, d tile instances, e1 (bin, Gaussian) candidates, t tiles, p pixels, bins of the
+    level-1 grid.  bin_local: the depth order is taken inside k_bin_build; otherwise four global passes over V precede."""
+    blocks = (n + 1023) // 1024                                   # level-1 blocks of 1024 items
+    table = 4 * bins * blocks                                     # hist[bin][block]
+    order = 0 if bin_local else 4 * (4 + 16) * v                  # 4 passes over V: histogram read 4 + (key, id) in 8 + out 8
+    items = 4 * n + 8 * v if bin_local else (4 + 4 + 8) * v       # tiles + boxes of the items (+ the order on the global path)
     return {
         # pos 12 + cov3d 24 per Gaussian; opacity 4 + SH 192 per visible; 52 B of attributes out; tiles 4
-        "preprocess": n * (12 + 24) + v * (4 + 192) + v * 52 + n * 4 + pre_extra,
-        # bins-per-Gaussian in, offsets out
-        "prefix_sum": 8 * scan_items,
-        # level-1 emit: count + offset per item, id + box per visible; (bin, id) per candidate
-        "preprocess_sort": 8 * dup_items + 12 * v + e1 * 8,
-        # depth order; one pass over the E1 candidates by bin; fill: candidate id 4 + box 8 in, Gaussian id 4 out per instance
-        "sort": order + (4 + 16) * e1 + 12 * e1 + 4 * d,
-        # per-tile counts: candidate id + box in; tile totals and ranges out
-        "tile_boundary": 12 * e1 + 12 * t,
+        "preprocess": n * (12 + 24) + v * (4 + 192) + v * 52 + n * 4,
+        # level-1 count + scan: the items in, the table out, then read and rewritten as prefixes
+        "prefix_sum": items + 3 * table,
+        # level-1 scatter: the items and the table in, one id per candidate out
+        "preprocess_sort": items + table + 4 * e1,
+        # (global depth order) + k_bin_build: id + depth + box per candidate in, one id per instance and the ranges out
+        "sort": order + (4 + 4 + 8) * e1 + 4 * d + 8 * t,
+        "tile_boundary": 0,                                       # produced inside k_bin_build
         "render": 40 * d + 16 * p,
     }
 
@@ -192,8 +199,9 @@ def main():
     if rank == 0:
         fps = world * args.steps / elapsed
         T = ((w + 15) // 16) * ((h + 15) // 16)
+        bin_edge, bins = bin_grid(w, h, int(os.environ.get("GS_BIN_SHIFT", 2)))
         nbytes = algorithmic_bytes(st.num_gaussians, st.num_visible, st.num_instances, st.num_bin_entries, T, w * h,
-                                   bin_local=int(st.sort_path) == 2)
+                                   bins, bin_local=int(st.sort_path) == 2)
         names = ["preprocess", "prefix_sum", "preprocess_sort", "sort", "tile_boundary", "render"]
         ms = {k: getattr(sums, "ms_" + k) / max(frames, 1) for k in names}
         per_pass = {k: {"ms": round(ms[k], 4), "alg_MB": round(nbytes[k] / 1e6, 2),
@@ -223,7 +231,7 @@ def main():
                        "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries), "tiles": T, "output": "rgba32f" + ("+bgra8" if args.bgra8 else ""),
                        "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}",
                        "depth_order_path": {1: "global", 2: "bin-local"}.get(int(st.sort_path), "?"),
-                       "max_bin_entries": int(st.max_bin_entries)},
+                       "max_bin_entries": int(st.max_bin_entries), "bins": bins, "bin_tiles": bin_edge},
             # the K-step region is timed `batches` times (each bracketed by barrier + synchronize); value / ms_per_step
             # are the median batch, spread = (max - min) / median over the batches
             "timed": {"batches": len(batch_s), "seconds": round(float(np.sum(batch_s)), 4),

@@ -130,6 +130,14 @@ int gs_scene_blob(const gs_scene* s, float** d_blob, uint64_t* floats);
 
 /* GSScene::getNumVertices (GSScene.h:37-39). */
 uint64_t gs_scene_num_vertices(const gs_scene* s);
+/* Opt-in storage quantisation (no reference counterpart; the reference keeps fp32 SH, GSScene.h:41-46): the 48 SH
+ * coefficients of every Gaussian are rounded to binary16 (nearest even) once, and preprocess reads 96 B instead of
+ * 192 B per visible Gaussian.  It CHANGES the scene: the result equals the reference pipeline run on the rounded
+ * coefficients (what the parity tests feed the oracle), not on the original ones.  gs_scene_sh_bits: 32 or 16. */
+int gs_scene_quantize_sh(gs_scene* s);
+int gs_scene_sh_bits(const gs_scene* s);
+/* Vertices [first, first + count) as GSScene::Vertex (60 floats each): spot checks of scenes too large to read back whole. */
+int gs_scene_download_vertex_range(const gs_scene* s, uint64_t first, uint64_t count, float* vertices);
 /* Read back the activated vertices as GSScene::Vertex[n] / cov3DBuffer as float[6n]. */
 int gs_scene_download_vertices(const gs_scene* s, float* vertices);
 int gs_scene_download_cov3d(const gs_scene* s, float* cov3d);
@@ -169,12 +177,19 @@ int gs_set_frames_in_flight(gs_renderer* r, int frames);
 /* How the per-tile lists get their depth order (same lists either way; no reference counterpart -- the reference
  * sorts all D instances, sort/hist.comp + sort/sort.comp):
  *   1  global:    the V visible Gaussians are ordered by depth first (12 small kernels), then binned;
- *   2  bin-local: candidates are binned in index order and every bin is ordered by one workgroup in LDS (one kernel);
+ *   2  bin-local: Gaussians are binned in index order (bins of S x S tiles, up to 32 x 32 of them) and the workgroup
+ *                 that builds a bin's tile lists first orders its candidates in LDS (6 kernels per frame);
  *                 a bin with more than 16384 candidates does not fit -> GS_ERR_OVERFLOW at the next synchronisation;
  *   0  automatic (default): bin-local, with a transparent re-run on the global path when a bin does not fit (and back
  *                 once the bins have fitted again for 32 frames).
  * The GS_STAGE_DEPTH_ORDER tap exists on path 1 only. */
 int gs_set_sort_path(gs_renderer* r, int mode);
+/* exp() of render.comp:77, which GLSL leaves to the implementation (3 + 2|x| ULP):
+ *   0  (default) the pipeline-defined polynomial: every pixel reproducible bit for bit on a CPU (the parity oracle);
+ *   1  the hardware's v_exp_f32 (what a Vulkan driver emits for exp()): ~10 % faster blend, pixels within a few
+ *      ULP of mode 0 apart from rare alpha-threshold flips (render.comp:78), still <= 1e-4 of the reference elsewhere.
+ * GS_EXP_MODE sets the initial mode for hosts that cannot call this (the viewer). */
+int gs_set_exp_mode(gs_renderer* r, int mode);
 /* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
  * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
 int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset);
@@ -185,10 +200,30 @@ int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, 
 int gs_get_frame_intervals(gs_renderer* r, float* out_ms, uint64_t capacity, uint64_t* n_out, int reset);
 /* Renderer::retrieveTimestamps (Renderer.cpp:85-100) for the last frame; synchronizes. */
 int gs_get_stats(gs_renderer* r, gs_frame_stats* out);
-/* Copy a stage buffer of the last frame to host memory; synchronizes. */
+/* Copy a stage buffer of the last frame to host memory; synchronizes.  The per-tile lists live bin-major in HBM;
+ * GS_STAGE_SORTED_GID / _SORTED_TILE / _RANGES present them laid end to end in tile order, i.e. as the reference's
+ * sorted payload, the tile half of its sorted keys and its tileBoundaryBuffer. */
 int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes);
 /* The hipStream_t the renderer enqueues on (for HIP-event timing by the caller). */
 void* gs_renderer_stream(gs_renderer* r);
+
+/* ---- multi-GPU: replicate the scene once, shard the camera poses (no per-frame collective) --------------------
+ * One process per GPU.  Rank 0 calls gs_dist_unique_id and hands the 128 bytes to the other ranks out of band (a
+ * file, a socket, MPI, torch.distributed ...); every rank calls gs_dist_create; the root loads the scene
+ * (gs_scene_load_ply) and every rank calls gs_dist_broadcast_scene, which sends the Gaussian count and then the packed
+ * scene blob with ONE ncclBroadcast over xGMI (RCCL, loaded on first use) and returns the rank's resident scene
+ * (the root gets its own handle back; the others own a new scene with cov3D recomputed locally).  Pose i belongs
+ * to rank i mod world.  No reference counterpart: the reference renders on one physical device
+ * (VulkanContext.cpp:134-178, `-d`). */
+#define GS_DIST_ID_BYTES 128
+typedef struct gs_dist gs_dist;
+int gs_dist_unique_id(uint8_t id[GS_DIST_ID_BYTES]);
+int gs_dist_create(const uint8_t id[GS_DIST_ID_BYTES], int rank, int world, int device, gs_dist** out);
+int gs_dist_rank(const gs_dist* d);
+int gs_dist_world(const gs_dist* d);
+uint64_t gs_dist_pose_count(const gs_dist* d, uint64_t poses);  /* how many of `poses` poses this rank renders */
+int gs_dist_broadcast_scene(gs_dist* d, gs_scene* mine /* root only */, int root, gs_scene** out);
+void gs_dist_destroy(gs_dist* d);
 
 #ifdef __cplusplus
 }

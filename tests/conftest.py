@@ -42,3 +42,10 @@ def _sort_path(request, monkeypatch):
     if param is not None:
         monkeypatch.setenv("GS_SORT_PATH", param)
     return param
+
+
+def pytest_collection_modifyitems(config, items):
+    """No GPU test may hold a box for long: a hung kernel must fail the test, not burn the GPU budget."""
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(600))

@@ -44,12 +44,33 @@ def test_committed_bench_line_has_every_contract_field():
 
 def test_algorithmic_bytes_model():
     m = _bench_module()
-    n, v, d, e1, t, p = 1_000_000, 483_640, 4_893_565, 741_254, 8160, 1920 * 1080
-    g = m.algorithmic_bytes(n, v, d, e1, t, p, bin_local=False)
-    b = m.algorithmic_bytes(n, v, d, e1, t, p, bin_local=True)
+    n, v, d, e1, t, p = 1_000_000, 483_640, 4_893_565, 1_082_561, 8160, 1920 * 1080
+    assert m.bin_grid(1920, 1080) == (4, 30 * 17) and m.bin_grid(3840, 2160) == (8, 30 * 17)
+    assert m.bin_grid(256, 256) == (4, 16) and m.bin_grid(7680, 4320) == (16, 30 * 17)
+    g = m.algorithmic_bytes(n, v, d, e1, t, p, 510, bin_local=False)
+    b = m.algorithmic_bytes(n, v, d, e1, t, p, 510, bin_local=True)
     assert g["render"] == b["render"] == 40 * d + 16 * p
-    assert g["tile_boundary"] == b["tile_boundary"] == 12 * e1 + 12 * t
-    assert g["preprocess"] == n * 40 + v * 248 and b["preprocess"] == g["preprocess"] + 4 * n
-    assert g["sort"] - b["sort"] == 80 * v - 12 * e1  # four global passes over V against one in-LDS order of E1
-    assert g["prefix_sum"] == 8 * v and b["prefix_sum"] == 8 * n
-    assert all(x > 0 for x in list(g.values()) + list(b.values()))
+    assert g["preprocess"] == b["preprocess"] == n * 40 + v * 248
+    assert g["sort"] - b["sort"] == 80 * v                      # four global passes over V on the global path only
+    assert b["sort"] == 16 * e1 + 4 * d + 8 * t
+    assert g["tile_boundary"] == b["tile_boundary"] == 0
+    assert b["prefix_sum"] == 4 * n + 8 * v + 3 * 4 * 510 * 977
+    assert all(x >= 0 for x in list(g.values()) + list(b.values()))
+
+
+def test_workload_names_follow_the_arguments():
+    m = _bench_module()
+    assert "configs[1]" in m.workload_name(1_000_000, 1920, 1080, 1)
+    assert "configs[3]" in m.workload_name(1_000_000, 1920, 1080, 8)
+    assert "configs[4]" in m.workload_name(6_000_000, 3840, 2160, 1)
+    assert "configs[2]" in m.workload_name(6_000_000, 1920, 1080, 1) and "stand-in" in m.workload_name(6_000_000, 1920, 1080, 1)
+    assert "not a BASELINE config" in m.workload_name(123, 640, 480, 1)
+
+
+def test_roofline_block_without_counters_is_the_hbm_view(pkg):
+    """Counters of other kernel sources must not be quoted: the block falls back to the live HBM view."""
+    m = _bench_module()
+    r = m.roofline(pkg, "render", 12345, 640, 480, 228_920_200, 0.25, 0.21)   # no counter file for this workload
+    assert r["bound"] == "hbm" and r["traffic"] is None and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] - 228_920_200 / 1e9 / 0.25e-3) < 1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    assert r["one_in_flight"]["ms"] == 0.21

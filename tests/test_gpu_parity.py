@@ -67,13 +67,27 @@ def test_hip_against_the_reference_shader_text(pkg, oracle, gpu):
               f"{[(x, y, round(d, 6)) for x, y, d, _ in flips]}")
 
 
-@pytest.mark.parametrize("w,h", [(200, 120), (33, 17), (16, 16), (1, 1), (641, 359), (4100, 2200), (7680, 4320)])
+@pytest.mark.parametrize("w,h", [(200, 120), (33, 17), (16, 16), (1, 1), (641, 359), (4100, 2200), (7680, 4320),
+                                 (16384, 48)])
 def test_ragged_resolutions(pkg, oracle, gpu, w, h):
-    """Odd sizes, single-tile frames, and the three bin sizes of the tile binning (8x8, 16x16, 32x32 tiles)."""
+    """Odd sizes, single-tile frames, and every bin size of the tile binning (4x4, 8x8, 16x16, 32x32 tiles; both
+    widths of the padded bin grid)."""
     rec = pkg.synth.synth_records(3000, seed=3, kind="A")
     scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
     compare_stages(pkg, rend, u, ref)
     assert np.abs(img - ref["image"]).max() <= PIXEL_TOL
+
+
+@pytest.mark.parametrize("shift", [2, 3, 4, 5])
+def test_every_bin_size_on_one_frame(pkg, oracle, gpu, monkeypatch, shift):
+    """GS_BIN_SHIFT forces bins of 4, 8, 16 and 32 tiles on the same 1080p frame (k_bin_build<1>, <1>, <4>, <16>;
+    30 x 17 down to 4 x 3 bins): identical lists, ranges and pixels."""
+    monkeypatch.setenv("GS_BIN_SHIFT", str(shift))
+    rec = pkg.synth.synth_records(30000, seed=17, kind="A")
+    rec[:40, 55:58] = 0.5  # a few splats that cover many bins
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, 1920, 1080)
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
 
 
 def test_rotated_translated_camera(pkg, oracle, gpu):
@@ -337,6 +351,7 @@ def _dense_bin_records(pkg, n=20000):
     rec = pkg.synth.synth_records(n, seed=9, kind="A")
     rec[:, 0] = rec[:, 0] * 0.02 + 0.3
     rec[:, 1] = rec[:, 1] * 0.02 - 0.2
+    rec[:, 2] = -4.0 + 0.05 * rec[:, 2]  # a thin slab: every splat's tile box lands in the same bins
     return rec
 
 
@@ -479,3 +494,67 @@ def test_needle_gaussians(pkg, oracle, gpu):
         scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
         compare_stages(pkg, rend, u, ref)
         np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+
+
+def test_fp16_sh_storage_is_the_pipeline_on_rounded_coefficients(pkg, oracle, gpu):
+    """gs_scene_quantize_sh (opt-in): preprocess reads binary16 SH.  The frame must equal, bit for
+    bit, the reference pipeline run on the coefficients rounded to binary16 (nearest even) -- the oracle is fed
+    exactly those -- and differ from the fp32 frame by no more than the rounding suggests."""
+    rec = pkg.synth.synth_records(20000, seed=61, kind="A")
+    rec[:50, 9:54] *= 1e-5  # some coefficients in binary16's subnormal range
+    w, h = 640, 360
+    verts = oracle.activate_records(rec)
+    u_ref = oracle.camera_uniforms(oracle.default_camera(), w, h)
+    ref32 = oracle.stages(verts, u_ref)
+    verts16 = verts.copy()
+    verts16["sh"] = verts["sh"].astype(np.float16).astype(np.float32)
+    ref16 = oracle.stages(verts16, u_ref)
+    scene = pkg.Scene.from_records(rec, device=0)
+    assert scene.sh_bits == 32
+    rend = pkg.Renderer(scene)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    img32, _ = rend.render_host(u)
+    np.testing.assert_array_equal(img32.view(np.uint32), ref32["image"].view(np.uint32))
+    scene.quantize_sh()
+    assert scene.sh_bits == 16
+    img16, _ = rend.render_host(u)
+    compare_stages(pkg, rend, u, ref16)
+    np.testing.assert_array_equal(img16.view(np.uint32), ref16["image"].view(np.uint32))
+    d = np.abs(img16 - img32).max()
+    assert 0 < d < 5e-3, d  # binary16 keeps 11 bits of each coefficient
+    rend.close()
+    scene.close()
+
+
+def test_ply_larger_than_4_gib(pkg, oracle, gpu, tmp_path):
+    """A 4.4 GiB PLY (17.9 M records; sparse on disk): the reference's Buffer takes a uint32_t size (Buffer.h:15) and
+    would truncate; here offsets are 64-bit end to end -- header, mmap, chunked streaming, the blob.  Records are
+    planted before, across and after the 4 GiB mark and read back from HBM."""
+    n = 17_900_000
+    path = str(tmp_path / "big.ply")
+    header = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n +
+              "".join("property float %s\n" % p for p in pkg.synth._PROPS) + "end_header\n").encode()
+    rec = pkg.synth.synth_records(6, seed=71, kind="A")
+    where = [0, 1, (1 << 32) // 248, (1 << 32) // 248 + 1, n - 2, n - 1]  # record 17 318 416 straddles byte 2^32
+    with open(path, "wb") as f:
+        f.write(header)
+        f.truncate(len(header) + n * 248)
+        for r, i in zip(rec, where):
+            f.seek(len(header) + i * 248)
+            f.write(r.astype("<f4").tobytes())
+    assert os.path.getsize(path) > (1 << 32)
+    try:
+        scene = pkg.Scene.load_ply(path, device=0)
+    except pkg.GsError as e:  # a box without 4.3 GiB to spare for the blob is not what is under test
+        if e.code == -4:
+            pytest.skip("not enough device memory for a 17.9 M-Gaussian scene")
+        raise
+    assert scene.num_vertices == n
+    want = oracle.activate_records(rec).view(np.float32).reshape(-1, 60)
+    for k, i in enumerate(where):
+        got = scene.download_vertex_range(i, 1)[0]
+        np.testing.assert_array_equal(got.view(np.uint32), want[k].view(np.uint32), err_msg=f"record {i}")
+    # an untouched record (all zero bytes): exp(0) scales, sigmoid(0) opacity, zero position
+    z = scene.download_vertex_range(12345678, 1)[0]
+    assert z[4] == 1.0 and z[5] == 1.0 and z[6] == 1.0 and z[7] == 0.5 and not z[:3].any()
+    scene.close()
