@@ -43,7 +43,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_scene_num_vertices", "gs_scene_quantize_sh", "gs_scene_sh_bits", "gs_scene_download_vertex_range",
            "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
-           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_get_timing_totals",
+           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_get_timing_totals",
            "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_renderer_stream",
            "gs_dist_unique_id", "gs_dist_create", "gs_dist_rank", "gs_dist_world", "gs_dist_pose_count",
            "gs_dist_broadcast_scene", "gs_dist_destroy"]
@@ -54,7 +54,8 @@ class FrameStats(C.Structure):
                 ("instance_capacity", C.c_uint64), ("ms_preprocess", C.c_float), ("ms_prefix_sum", C.c_float),
                 ("ms_preprocess_sort", C.c_float), ("ms_sort", C.c_float), ("ms_tile_boundary", C.c_float),
                 ("ms_render", C.c_float), ("ms_total", C.c_float), ("retries", C.c_uint32),
-                ("num_bin_entries", C.c_uint32), ("max_bin_entries", C.c_uint32), ("sort_path", C.c_uint32)]
+                ("num_bin_entries", C.c_uint32), ("max_bin_entries", C.c_uint32), ("sort_path", C.c_uint32),
+                ("bin_tiles", C.c_uint32), ("sort_level", C.c_uint32), ("pad_", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -250,6 +251,10 @@ class Renderer:
     def set_exp_mode(self, mode):
         """0 pipeline-defined exp (exact), 1 hardware v_exp_f32 (gs_set_exp_mode)."""
         _check(lib().gs_set_exp_mode(self._h, C.c_int(int(mode))))
+
+    def set_graph_mode(self, enabled):
+        """Replay frames as captured HIP graphs (gs_set_graph_mode)."""
+        _check(lib().gs_set_graph_mode(self._h, C.c_int(int(bool(enabled)))))
 
     def set_sort_path(self, mode):
         """0 automatic, 1 global depth order, 2 bin-local (gs_set_sort_path)."""

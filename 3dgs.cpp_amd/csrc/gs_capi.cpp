@@ -438,6 +438,10 @@ void load_ply_streamed(gs_scene* s, const std::string& path) {
 // VALU-bound blend of frame i on the same GPU.
 struct FrameBuffers {
     hipStream_t stream = nullptr;
+    // CU-partition experiment (GS_CU_MASK_PREP / GS_CU_MASK_BLEND): the blend runs on its own CU-masked stream
+    hipStream_t blend_stream = nullptr;
+    hipEvent_t prep_done = nullptr, blend_done = nullptr;
+    bool blend_recorded = false;
     // per-Gaussian attributes
     DevBuf<uint32_t> tiles;
     DevBuf<float> depth, radius, bch;
@@ -452,12 +456,36 @@ struct FrameBuffers {
     DevBuf<uint32_t> sorted;              // [capacity + 4] per-tile lists, bin-major
     DevBuf<uint32_t> ranges;              // [T][2]
     DevBuf<gs::Counters> counters;
+    // HIP-graph replay (gs_set_graph_mode): the frame's fixed-shape launches captured once per configuration
+    DevBuf<gs::FrameParams> params;
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey {
+        int level = -1, hw_exp = 0;
+        uint32_t width = 0, height = 0, capacity = 0;
+        const void *tile_order = nullptr, *ranges = nullptr, *sh16 = nullptr;
+        bool operator==(const GraphKey& o) const {
+            return level == o.level && hw_exp == o.hw_exp && width == o.width && height == o.height &&
+                   capacity == o.capacity && tile_order == o.tile_order && ranges == o.ranges && sh16 == o.sh16;
+        }
+    } graph_key;
+    void drop_graph() {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        graph_exec = nullptr;
+        graph_key = GraphKey{};
+    }
     size_t n = 0;
     bool ready = false;
 
-    void init(size_t n_, uint32_t capacity) {
+    void init(size_t n_, uint32_t capacity, const std::vector<uint32_t>& mask_prep, const std::vector<uint32_t>& mask_blend) {
         n = n_;
-        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (!mask_prep.empty() && !mask_blend.empty()) {
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, static_cast<uint32_t>(mask_prep.size()), mask_prep.data()));
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&blend_stream, static_cast<uint32_t>(mask_blend.size()), mask_blend.data()));
+            HIP_CHECK(hipEventCreateWithFlags(&prep_done, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&blend_done, hipEventDisableTiming));
+        } else {
+            HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        }
         tiles.alloc(n);
         depth.alloc(n);
         radius.alloc(n);
@@ -465,9 +493,10 @@ struct FrameBuffers {
         aabb.alloc(n);
         conic_op.alloc(n);
         uv_rg.alloc(n);
-        l1_hist.alloc(1024 * static_cast<size_t>(gs::bin_level1_blocks(static_cast<uint32_t>(n))));
+        l1_hist.alloc(1025 * static_cast<size_t>(gs::bin_level1_blocks(static_cast<uint32_t>(n))));  // + the row of visible counts
         bin_count.alloc(1024);
         counters.alloc(1);
+        params.alloc(1);
         set_capacity(capacity);
         ready = true;
     }
@@ -481,6 +510,7 @@ struct FrameBuffers {
         digit_total.alloc(256);
     }
     void set_capacity(uint32_t cap) {
+        drop_graph();  // the captured launches hold the old buffers
         cand.alloc(cap);
         // a frame whose candidates overflow the capacity leaves a gap of unwritten entries that k_bin_build still
         // gathers through before the frame is re-run: the gap must hold valid Gaussian ids (0), never whatever
@@ -488,8 +518,16 @@ struct FrameBuffers {
         HIP_CHECK(hipMemset(cand.p, 0, static_cast<size_t>(cap) * sizeof(uint32_t)));
         sorted.alloc(static_cast<size_t>(cap) + 4);  // + 4: a 16-byte list store that starts inside the capacity may end past it
     }
+    void sync() const {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (blend_stream) HIP_CHECK(hipStreamSynchronize(blend_stream));
+    }
     ~FrameBuffers() {
+        drop_graph();
         if (stream) (void)hipStreamDestroy(stream);
+        if (blend_stream) (void)hipStreamDestroy(blend_stream);
+        if (prep_done) (void)hipEventDestroy(prep_done);
+        if (blend_done) (void)hipEventDestroy(blend_done);
     }
 };
 
@@ -500,8 +538,10 @@ struct FrameSlot {
     hipEvent_t ev[9] = {};
     hipEvent_t done = nullptr;
     gs::Counters* h_counters = nullptr;  // pinned
+    gs::FrameParams* h_params = nullptr;  // pinned staging of the frame's parameter block (graph replay)
     bool timed = false;
     int level = 0;  // the depth-order level this frame ran at (gs_renderer::level)
+    int bin_shift = 3;
 };
 
 struct gs_renderer {
@@ -525,18 +565,21 @@ struct gs_renderer {
 
     gs_frame_stats last{};  // stats of the most recently retired frame
 
-    // How a frame's per-tile lists get their depth order.  level 0 / 1: bin-local -- the
-    // workgroup that builds a bin's lists orders its candidates in LDS first (up to 4096 / 16384 per bin; 6 kernels per
-    // frame); level 2: global -- the V visible Gaussians are ordered first (12 more kernels; any bin size).
-    // sort_mode 0 = automatic: start at level 0; a bin that does not fit re-runs the frame one level up; after 32
-    // frames that would have fitted the level below, go back down.
+    // How a frame's per-tile lists get their depth order.  level 0 / 1 / 2: bin-local -- the
+    // workgroup that builds a bin's lists orders its candidates in LDS first (up to 4096 / 8192 / 16384 per bin; 6 kernels
+    // per frame); level 3: global -- the V visible Gaussians are ordered first (12 more kernels; any bin size).
+    // sort_mode 0 = automatic: start at level 0; a bin that does not fit re-runs the frame at the level its size asks
+    // for; after 32 frames that would have fitted the level below, go back down.
     int sort_mode = 0;           // 0 auto, 1 global depth order, 2 bin-local (forced: a bin beyond 16384 is an error)
     int level = 0;
     uint32_t frames_since_fallback = 0;
-    static uint32_t level_limit(int lv) { return lv == 0 ? gs::kBinSortSmall : gs::kBinSortMax; }
-    int frame_level() const { return sort_mode == 1 ? 2 : level; }
+    static constexpr int kGlobalLevel = 3;
+    static uint32_t level_limit(int lv) { return static_cast<uint32_t>(gs::kBinSortSmall) << lv; }
+    int frame_level() const { return sort_mode == 1 ? kGlobalLevel : level; }
+    bool graph_mode = false;     // replay each frame as one captured HIP graph (gs_set_graph_mode)
     bool hw_exp = false;         // blend with the hardware's v_exp_f32 instead of the pipeline-defined exp (gs_set_exp_mode)
-    int min_bin_shift = 2;       // GS_BIN_SHIFT: log2 of the smallest bin edge in tiles
+    int min_bin_shift = 3;       // GS_BIN_SHIFT: log2 of the default bin edge in tiles (8 x 8 tiles)
+    bool refined = false;        // bins of half that edge: taken when a bin outgrows the largest in-LDS order
     bool have_frame = false;
     uint32_t retries = 0;        // lifetime count of re-run frames (statistics only)
     uint32_t redo_chain = 0;     // consecutive re-runs since a frame last retired cleanly: the runaway guard
@@ -558,6 +601,7 @@ struct gs_renderer {
                 if (e) (void)hipEventDestroy(e);
             if (sl.done) (void)hipEventDestroy(sl.done);
             if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+            if (sl.h_params) (void)hipHostFree(sl.h_params);
         }
     }
 
@@ -576,17 +620,36 @@ struct gs_renderer {
             HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(gs::Counters), hipHostMallocDefault));
             *sl.h_counters = gs::Counters{};
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_params), sizeof(gs::FrameParams), hipHostMallocDefault));
         }
         uint64_t want = std::max<uint64_t>(1u << 20, 8 * static_cast<uint64_t>(scene->n));
         // test knob: start small so that the overflow / grow / re-run machinery is exercised by small scenes
         if (const char* e = std::getenv("GS_INITIAL_CAPACITY")) want = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
         capacity = static_cast<uint32_t>(std::min<uint64_t>(want, kMaxInstances));
-        sets[0].init(scene->n, capacity);
+        parse_cu_masks();
+        sets[0].init(scene->n, capacity, mask_prep, mask_blend);
+    }
+
+    // Experiment: GS_CU_MASK_PREP / GS_CU_MASK_BLEND = hex strings, most significant CU first,
+    // 256 bits each.  With both set, a frame's passes before the blend run on a stream restricted to the first mask and
+    // the blend on a stream restricted to the second, chained by events.
+    std::vector<uint32_t> mask_prep, mask_blend;
+    static std::vector<uint32_t> parse_mask(const char* hex) {
+        std::vector<uint32_t> words;
+        if (!hex) return words;
+        std::string h(hex);
+        while (h.size() % 8) h.insert(h.begin(), '0');
+        for (size_t i = h.size(); i >= 8; i -= 8) words.push_back(static_cast<uint32_t>(std::stoul(h.substr(i - 8, 8), nullptr, 16)));
+        return words;
+    }
+    void parse_cu_masks() {
+        mask_prep = parse_mask(std::getenv("GS_CU_MASK_PREP"));
+        mask_blend = parse_mask(std::getenv("GS_CU_MASK_BLEND"));
     }
 
     void set_num_sets(int k) {
         for (int i = 0; i < k; ++i)
-            if (!sets[i].ready) sets[i].init(scene->n, capacity);
+            if (!sets[i].ready) sets[i].init(scene->n, capacity, mask_prep, mask_blend);
         num_sets = k;
     }
 
@@ -635,18 +698,29 @@ struct gs_renderer {
         int bin_shift, grid_shift;
         uint32_t bins_x, bins_y;
     };
+    static bool grid_fits(uint32_t tx, uint32_t ty, int s) { return (((tx - 1) >> s) + 1) <= 32 && (((ty - 1) >> s) + 1) <= 32; }
+    // the coarsest-allowed choice: bins of 8 x 8 tiles (or GS_BIN_SHIFT), larger only to keep the grid within 32 x 32
+    static int base_shift(uint32_t tx, uint32_t ty, int min_shift) {
+        int s = std::max(2, min_shift);
+        while (!grid_fits(tx, ty, s)) ++s;
+        return s;
+    }
     BinGeometry bin_geometry(uint32_t tx, uint32_t ty) const {
-        // smallest S >= 4 tiles that keeps the grid within 32 x 32 (more, smaller bins: shorter in-LDS sorts, more
-        // workgroups); GS_BIN_SHIFT (renderer creation) raises it for experiments
-        int s = std::max(2, min_bin_shift);
-        while ((((tx - 1) >> s) + 1) > 32 || (((ty - 1) >> s) + 1) > 32) ++s;
+        int s = base_shift(tx, ty, min_bin_shift);
         if (s > 5) throw Error(GS_ERR_INVALID, "resolution too large for the tile binning (max 16384 x 16384)");
+        // `refined`: a bin outgrew the largest in-LDS order -> bins of half the edge (a quarter of the candidates or so)
+        if (refined && s > 2 && grid_fits(tx, ty, s - 1)) --s;
         BinGeometry g;
         g.bin_shift = s;
         g.bins_x = ((tx - 1) >> s) + 1;
         g.bins_y = ((ty - 1) >> s) + 1;
         g.grid_shift = (g.bins_x <= 16 && g.bins_y <= 16) ? 4 : 5;
         return g;
+    }
+    bool can_refine(const gs_uniforms& u) const {
+        const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
+        const int s = base_shift(tx, ty, min_bin_shift);
+        return !refined && s > 2 && s <= 5 && grid_fits(tx, ty, s - 1);
     }
 
     void enqueue(const gs_uniforms& u, float* d_rgba, uint8_t* d_bgra) {
@@ -662,7 +736,7 @@ struct gs_renderer {
         const uint64_t nt = static_cast<uint64_t>(tx) * ty;
         const BinGeometry geo = bin_geometry(tx, ty);
         const int lv = frame_level();
-        const bool bin_local = lv < 2;
+        const bool bin_local = lv < kGlobalLevel;
         if (2 * nt > fb.ranges.n || (!bin_local && !fb.dkeys[0].p)) {
             drain();  // (re)allocation: wait for queued frames that still use the old buffers
             fb.ranges.ensure(2 * nt);
@@ -683,90 +757,134 @@ struct gs_renderer {
             HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(gs::Counters), stream));
             HIP_CHECK(hipMemsetAsync(fb.ranges.p, 0, 2 * nt * sizeof(uint32_t), stream));  // no Gaussians: every tile (0, 0)
         }
-        HIP_CHECK(hipEventRecord(ev[0], stream));
-        gs::launch_preprocess(sv, u, av, cnt, stream);
-        if (timing) HIP_CHECK(hipEventRecord(ev[1], stream));
-
-        if (!bin_local && n != 0) {
-            // ---- global depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
-            const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (n + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
-            const uint32_t* kin = reinterpret_cast<const uint32_t*>(fb.depth.p);
-            const uint32_t* vin = nullptr;
-            for (int pass = 0; pass < 4; ++pass) {
-                gs::RadixPass p{};
-                const int dst = pass & 1;
-                p.keys_in = kin;
-                p.vals_in = vin;
-                p.keys_out = fb.dkeys[dst].p;
-                p.vals_out = fb.dvals[dst].p;
-                p.n_in = &cnt->visible;
-                p.n_static = n;
-                p.tiles = fb.tiles.p;
-                p.n_out = &cnt->visible;
-                p.block_hist = fb.block_hist.p;
-                p.digit_total = fb.digit_total.p;
-                p.shift = pass * 8;
-                p.bits = 8;
-                p.blocks = blocks;
-                p.first = pass == 0;
-                gs::launch_radix_pass(p, stream);
-                kin = fb.dkeys[dst].p;
-                vin = fb.dvals[dst].p;
+        if (fb.blend_stream && fb.blend_recorded) HIP_CHECK(hipStreamWaitEvent(stream, fb.blend_done, 0));  // the set's previous blend
+        // the frame's launches; `fp` non-null = replayable form (per-frame values read from fb.params), no span events
+        auto passes = [&](const gs::FrameParams* fp, bool spans, hipStream_t bstream) {
+            gs::launch_preprocess(sv, u, av, cnt, fp, stream);
+            if (spans) HIP_CHECK(hipEventRecord(ev[1], stream));
+            if (!bin_local && n != 0) {
+                // ---- global depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
+                const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (n + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
+                const uint32_t* kin = reinterpret_cast<const uint32_t*>(fb.depth.p);
+                const uint32_t* vin = nullptr;
+                for (int pass = 0; pass < 4; ++pass) {
+                    gs::RadixPass p{};
+                    const int dst = pass & 1;
+                    p.keys_in = kin;
+                    p.vals_in = vin;
+                    p.keys_out = fb.dkeys[dst].p;
+                    p.vals_out = fb.dvals[dst].p;
+                    p.n_in = &cnt->visible;
+                    p.n_static = n;
+                    p.tiles = fb.tiles.p;
+                    p.n_out = &cnt->visible;
+                    p.block_hist = fb.block_hist.p;
+                    p.digit_total = fb.digit_total.p;
+                    p.shift = pass * 8;
+                    p.bits = 8;
+                    p.blocks = blocks;
+                    p.first = pass == 0;
+                    gs::launch_radix_pass(p, stream);
+                    kin = fb.dkeys[dst].p;
+                    vin = fb.dvals[dst].p;
+                }
             }
-            depth_order = fb.dvals[1].p;
-        } else {
-            depth_order = nullptr;
-        }
-        if (timing) HIP_CHECK(hipEventRecord(ev[2], stream));
-
-        if (n != 0) {
-            gs::BinLaunch b{};
-            b.order = bin_local ? nullptr : depth_order;
-            b.n_items = bin_local ? nullptr : &cnt->visible;
-            b.n_bound = n;
-            b.tiles = fb.tiles.p;
-            b.aabb = fb.aabb.p;
-            b.depth = fb.depth.p;
-            b.hist = fb.l1_hist.p;
-            b.bin_count = fb.bin_count.p;
-            b.cand = fb.cand.p;
-            b.ranges = fb.ranges.p;
-            b.sorted_gid = fb.sorted.p;
-            b.counters = cnt;
-            b.capacity = capacity;
-            b.tiles_x = tx;
-            b.tiles_y = ty;
-            b.bins_x = geo.bins_x;
-            b.bins_y = geo.bins_y;
-            b.bin_shift = geo.bin_shift;
-            b.grid_shift = geo.grid_shift;
-            // ---- level 1: which Gaussian touches which bin (count + scan, then the per-bin candidate lists) ----
-            gs::launch_bin_level1_count(b, stream);
-            if (timing) HIP_CHECK(hipEventRecord(ev[3], stream));
-            gs::launch_bin_level1_scatter(b, stream);
-            if (timing) HIP_CHECK(hipEventRecord(ev[4], stream));
-            // ---- level 2: order inside the bin (bin-local path), tile ranges, per-tile lists ----
-            gs::launch_bin_level2(b, lv, stream);
-        } else if (timing) {
-            HIP_CHECK(hipEventRecord(ev[3], stream));
-            HIP_CHECK(hipEventRecord(ev[4], stream));
-        }
-        if (timing) HIP_CHECK(hipEventRecord(ev[5], stream));
+            if (spans) HIP_CHECK(hipEventRecord(ev[2], stream));
+            if (n != 0) {
+                gs::BinLaunch b{};
+                b.order = bin_local ? nullptr : fb.dvals[1].p;
+                b.n_items = bin_local ? nullptr : &cnt->visible;
+                b.n_bound = n;
+                b.tiles = fb.tiles.p;
+                b.aabb = fb.aabb.p;
+                b.depth = fb.depth.p;
+                b.hist = fb.l1_hist.p;
+                b.bin_count = fb.bin_count.p;
+                b.cand = fb.cand.p;
+                b.ranges = fb.ranges.p;
+                b.sorted_gid = fb.sorted.p;
+                b.counters = cnt;
+                b.capacity = capacity;
+                b.tiles_x = tx;
+                b.tiles_y = ty;
+                b.bins_x = geo.bins_x;
+                b.bins_y = geo.bins_y;
+                b.bin_shift = geo.bin_shift;
+                b.grid_shift = geo.grid_shift;
+                // ---- level 1: which Gaussian touches which bin (count + scan, then the per-bin candidate lists) ----
+                gs::launch_bin_level1_count(b, stream);
+                if (spans) HIP_CHECK(hipEventRecord(ev[3], stream));
+                gs::launch_bin_level1_scatter(b, bin_local && geo.bin_shift <= 3, stream);
+                if (spans) HIP_CHECK(hipEventRecord(ev[4], stream));
+                // ---- level 2: order inside the bin (bin-local path), tile ranges, per-tile lists ----
+                gs::launch_bin_level2(b, lv, stream);
+            } else if (spans) {
+                HIP_CHECK(hipEventRecord(ev[3], stream));
+                HIP_CHECK(hipEventRecord(ev[4], stream));
+            }
+            if (spans) HIP_CHECK(hipEventRecord(ev[5], stream));
+            // ---- blend ----
+            if (bstream != stream) {
+                HIP_CHECK(hipEventRecord(fb.prep_done, stream));
+                HIP_CHECK(hipStreamWaitEvent(bstream, fb.prep_done, 0));
+            }
+            gs::launch_blend(fb.ranges.p, fb.sorted.p, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
+                             fused_counters ? sl.h_counters : nullptr, hw_exp, fp, bstream);
+        };
+        depth_order = bin_local ? nullptr : fb.dvals[1].p;
         sorted_gid = fb.sorted.p;
-
-        // ---- blend ----
-        gs::launch_blend(fb.ranges.p, sorted_gid, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
-                         fused_counters ? sl.h_counters : nullptr, hw_exp, stream);
-        HIP_CHECK(hipEventRecord(ev[7], stream));
-        if (!fused_counters) HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipEventRecord(sl.done, stream));
+        hipStream_t bstream = fb.blend_stream ? fb.blend_stream : stream;
+        const bool replay = graph_mode && fused_counters && !fb.blend_stream;
+        if (replay) {
+            *sl.h_params = gs::FrameParams{u, d_rgba, d_bgra, sl.h_counters};
+            HIP_CHECK(hipMemcpyAsync(fb.params.p, sl.h_params, sizeof(gs::FrameParams), hipMemcpyHostToDevice, stream));
+            FrameBuffers::GraphKey key;
+            key.level = lv;
+            key.hw_exp = hw_exp ? 1 : 0;
+            key.width = u.width;
+            key.height = u.height;
+            key.capacity = capacity;
+            key.tile_order = tile_order.p;
+            key.ranges = fb.ranges.p;
+            key.sh16 = sv.sh16;
+            if (!fb.graph_exec || !(key == fb.graph_key)) {  // first frame of this configuration: capture its launches
+                fb.drop_graph();
+                hipGraph_t graph = nullptr;
+                HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    passes(fb.params.p, false, stream);
+                } catch (...) {
+                    (void)hipStreamEndCapture(stream, &graph);
+                    if (graph) (void)hipGraphDestroy(graph);
+                    throw;
+                }
+                HIP_CHECK(hipStreamEndCapture(stream, &graph));
+                const hipError_t e = hipGraphInstantiate(&fb.graph_exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                HIP_CHECK(e);
+                fb.graph_key = key;
+            }
+            HIP_CHECK(hipEventRecord(ev[0], stream));
+            HIP_CHECK(hipGraphLaunch(fb.graph_exec, stream));
+        } else {
+            HIP_CHECK(hipEventRecord(ev[0], stream));
+            passes(nullptr, timing, bstream);
+        }
+        HIP_CHECK(hipEventRecord(ev[7], bstream));
+        if (!fused_counters) HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, bstream));
+        HIP_CHECK(hipEventRecord(sl.done, bstream));
+        if (fb.blend_stream) {
+            HIP_CHECK(hipEventRecord(fb.blend_done, bstream));
+            fb.blend_recorded = true;
+        }
         HIP_CHECK(hipGetLastError());
 
         sl.level = lv;
+        sl.bin_shift = geo.bin_shift;
         sl.u = u;
         sl.rgba = d_rgba;
         sl.bgra = d_bgra;
-        sl.timed = timing;
+        sl.timed = timing && !replay;
         ++frames_enqueued;
         ++pending;
     }
@@ -780,7 +898,7 @@ struct gs_renderer {
         HIP_CHECK(hipEventSynchronize(sl.done));
         if (sl.h_counters->overflow) {
             for (auto& fb : sets)
-                if (fb.ready) HIP_CHECK(hipStreamSynchronize(fb.stream));
+                if (fb.ready) fb.sync();
             struct Redo {
                 gs_uniforms u;
                 float* rgba;
@@ -798,7 +916,7 @@ struct gs_renderer {
                     // D instances and E1 level-1 candidates share the capacity
                     need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, q.h_counters->bin_entries));
                 }
-                if (q.level < 2 && (q.h_counters->overflow & 2u)) bin_too_big = true;
+                if (q.level < kGlobalLevel && (q.h_counters->overflow & 2u)) bin_too_big = true;
                 fullest = std::max(fullest, q.h_counters->max_bin);
             }
             const int failed_level = sl.level;
@@ -807,10 +925,17 @@ struct gs_renderer {
             pending = 0;
             prev_retired = false;
             if (bin_too_big) {  // a bin outgrew the in-LDS order of this level: one level up from here on
-                const int wanted = fullest > static_cast<uint32_t>(gs::kBinSortMax) ? 2 : std::max(1, failed_level + 1);
-                if (sort_mode == 2 && wanted >= 2)
-                    throw Error(GS_ERR_OVERFLOW, "a bin holds more candidates than the bin-local sort can order");
-                level = std::max(level, wanted);
+                int wanted = failed_level + 1;
+                while (wanted < kGlobalLevel && fullest > level_limit(wanted)) ++wanted;
+                if (wanted >= kGlobalLevel && can_refine(sl.u)) {  // smaller bins before giving up the bin-local path
+                    refined = true;
+                    wanted = kGlobalLevel - 1;
+                } else {
+                    if (sort_mode == 2 && wanted >= kGlobalLevel)
+                        throw Error(GS_ERR_OVERFLOW, "a bin holds more candidates than the bin-local sort can order");
+                    level = std::max(level, wanted);
+                }
+                if (refined) level = std::max(level, wanted);
                 frames_since_fallback = 0;
             }
             // runaway guard: one frame may need a path fall-back and a few grow steps (each grow is sized from the counts
@@ -835,6 +960,16 @@ struct gs_renderer {
             } else {
                 frames_since_fallback = 0;
             }
+        } else if (sort_mode != 1 && refined) {  // at the smallest order with the small bins: try the default bins again
+            if (sl.h_counters->max_bin <= level_limit(0) / 2) {  // four times the tiles per bin should still fit level 2
+                if (++frames_since_fallback >= 32) {
+                    refined = false;
+                    level = kGlobalLevel - 1;
+                    frames_since_fallback = 0;
+                }
+            } else {
+                frames_since_fallback = 0;
+            }
         }
         gs_frame_stats st{};
         st.num_gaussians = scene->n;
@@ -842,7 +977,9 @@ struct gs_renderer {
         st.num_instances = sl.h_counters->instances;
         st.num_bin_entries = sl.h_counters->bin_entries;
         st.max_bin_entries = sl.h_counters->max_bin;
-        st.sort_path = sl.level < 2 ? 2u : 1u;
+        st.sort_path = sl.level < kGlobalLevel ? 2u : 1u;
+        st.sort_level = static_cast<uint32_t>(sl.level);
+        st.bin_tiles = 1u << sl.bin_shift;
         st.instance_capacity = capacity;
         auto span = [&](int a, int b) {
             float ms = 0.0f;
@@ -1069,8 +1206,9 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
         auto r = std::make_unique<gs_renderer>();
         r->scene = scene;
         r->init();
+        if (const char* e = std::getenv("GS_GRAPH")) r->graph_mode = std::atoi(e) != 0;  // initial gs_set_graph_mode
         if (const char* e = std::getenv("GS_EXP_MODE")) r->hw_exp = std::atoi(e) != 0;  // initial gs_set_exp_mode
-        if (const char* e = std::getenv("GS_BIN_SHIFT")) r->min_bin_shift = std::min(5, std::max(2, std::atoi(e)));
+        if (const char* e = std::getenv("GS_BIN_SHIFT")) r->min_bin_shift = std::min(5, std::max(2, std::atoi(e)));  // default bin edge
         if (const char* e = std::getenv("GS_SORT_PATH")) {  // initial gs_set_sort_path, for hosts that cannot call it (the viewer)
             const int mode = std::atoi(e);
             if (mode < 0 || mode > 2) throw Error(GS_ERR_INVALID, "GS_SORT_PATH must be 0 (auto), 1 (global) or 2 (bin-local)");
@@ -1083,7 +1221,10 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
 void gs_renderer_destroy(gs_renderer* r) {
     if (r)
         for (auto& fb : r->sets)
-            if (fb.ready) (void)hipStreamSynchronize(fb.stream);
+            if (fb.ready) {
+                (void)hipStreamSynchronize(fb.stream);
+                if (fb.blend_stream) (void)hipStreamSynchronize(fb.blend_stream);
+            }
     delete r;
 }
 
@@ -1199,6 +1340,7 @@ int gs_set_sort_path(gs_renderer* r, int mode) {
         r->drain();
         r->sort_mode = mode;
         r->level = 0;
+        r->refined = false;
         r->frames_since_fallback = 0;
     });
 }
@@ -1209,6 +1351,16 @@ int gs_set_exp_mode(gs_renderer* r, int mode) {
         if (mode < 0 || mode > 1) throw Error(GS_ERR_INVALID, "exp mode must be 0 (pipeline-defined, exact) or 1 (hardware v_exp_f32)");
         r->drain();
         r->hw_exp = mode == 1;
+    });
+}
+
+int gs_set_graph_mode(gs_renderer* r, int enabled) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "renderer is null");
+        r->drain();
+        r->graph_mode = enabled != 0;
+        if (!r->graph_mode)
+            for (auto& fb : r->sets) fb.drop_graph();
     });
 }
 

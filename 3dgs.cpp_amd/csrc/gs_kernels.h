@@ -48,6 +48,16 @@ struct Counters {
     uint32_t max_bin;    // candidates in the fullest bin
     uint32_t pad;
 };
+// What changes from one frame to the next.  Normally these travel as kernel arguments; when a frame is replayed
+// as a captured HIP graph (gs_set_graph_mode) they are read from this block in device memory instead, which the
+// host refreshes with one small copy ahead of the graph launch -- the graph itself never needs re-recording.
+struct FrameParams {
+    gs_uniforms u;
+    float* rgba;
+    uint8_t* bgra;
+    Counters* host_counters;
+};
+
 constexpr int kBinSortSmall = 4096;  // candidates per bin the 256-thread k_bin_build orders in LDS
 constexpr int kBinSortMax = 16384;   // ... and the 1024-thread one (128 KiB of (key, id))
 
@@ -55,7 +65,9 @@ void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, 
 // fp32 SH block of the blob -> binary16 (round to nearest even), n x 48 values
 void launch_sh_to_half(const float* blob, uint16_t* sh16, uint32_t n, uint32_t stride, hipStream_t s);
 // counters (nullable): the kernel clears the frame's counters, so that a frame needs no memset node.
-void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters, hipStream_t s);
+// fp (nullable, device memory): read the uniforms / output pointers from it instead of the arguments (graph replay)
+void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
+                       const FrameParams* fp, hipStream_t s);
 
 // Stable LSD radix pass on (u32 key, u32 value) pairs, 8-bit digit at `shift` (the global depth order).
 //   first != 0: the input is (key = bits(depth[i]), value = i) for every i < n_static with tiles[i] != 0
@@ -90,7 +102,7 @@ struct BinLaunch {
     const uint32_t* tiles;      // [N]
     const ushort4* aabb;        // [N]
     const float* depth;         // [N]
-    uint32_t* hist;             // [padded bins][bin_level1_blocks(n_bound)]
+    uint32_t* hist;             // [padded bins + 1][bin_level1_blocks(n_bound)] (the last row: visible items per block)
     uint32_t* bin_count;        // [1024]
     uint32_t* cand;             // [capacity]
     uint32_t* ranges;           // [T][2]
@@ -104,16 +116,19 @@ struct BinLaunch {
 uint32_t bin_level1_blocks(uint32_t n_items);
 hipError_t bin_prepare_device();                                    // once per device, before the first launch_bin_level2
 void launch_bin_level1_count(const BinLaunch& b, hipStream_t s);    // k_l1_hist, k_l1_scan
-void launch_bin_level1_scatter(const BinLaunch& b, hipStream_t s);  // k_l1_scatter
-// variant 0: in-LDS order of up to kBinSortSmall candidates per bin (256-thread workgroups), 1: up to kBinSortMax
-// (1024 threads), 2: no ordering (the candidates arrive in depth order: global path), any bin size
-void launch_bin_level2(const BinLaunch& b, int variant, hipStream_t s);  // k_bin_build
+// any_order: the candidates of a bin may land in any order inside each block's run (the bin-local path with bins of
+// <= 8 x 8 tiles orders them by (depth, id) anyway); otherwise item order is kept
+void launch_bin_level1_scatter(const BinLaunch& b, bool any_order, hipStream_t s);  // k_l1_scatter / k_l1_scatter_any_order
+// level 0 / 1 / 2: the bin's candidates are ordered by (depth bits, id) in LDS, up to 4096 / 8192 / 16384 per bin;
+// level 3: no ordering (the candidates arrive in depth order: global path), any bin size
+void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s);  // k_bin_build
 
 // render.comp counterpart.
 // tile_order[b] = the tile workgroup b renders (a permutation of the tiles)
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
-                  Counters* host_counters /* pinned, nullable: *host_counters = *counters */, bool hw_exp, hipStream_t s);
+                  Counters* host_counters /* pinned, nullable: *host_counters = *counters */, bool hw_exp,
+                  const FrameParams* fp, hipStream_t s);
 
 }  // namespace gs

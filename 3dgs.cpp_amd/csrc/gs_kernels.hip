@@ -21,6 +21,12 @@
 namespace gs {
 
 #define WAVE 64
+#ifndef GS_DPP_TRANSPOSE
+#define GS_DPP_TRANSPOSE 1
+#endif
+#ifndef GS_L1_WORDLOOP
+#define GS_L1_WORDLOOP 1
+#endif
 #define BLOCK 256
 
 // ---------------------------------------------------------------------------------------
@@ -151,11 +157,12 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * 
 
 struct PreUniforms {
     gs_uniforms u;
-    Counters* counters;  // nullable
+    Counters* counters;      // nullable
+    const FrameParams* fp;   // nullable: the uniforms live there (graph replay)
 };
 
 __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms pu, AttrView av) {
-    const gs_uniforms& u = pu.u;
+    const gs_uniforms& u = pu.fp ? pu.fp->u : pu.u;  // uniform either way: scalar loads
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= sv.n) return;
     if (i == 0 && pu.counters) {  // first kernel of the frame: the counters the later kernels accumulate into
@@ -348,11 +355,12 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
 }
 
 void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
-                       hipStream_t s) {
+                       const FrameParams* fp, hipStream_t s) {
     if (sv.n == 0) return;
     PreUniforms pu;
     pu.u = u;
     pu.counters = counters;
+    pu.fp = fp;
     hipLaunchKernelGGL(k_preprocess, dim3((sv.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, sv, pu, av);
 }
 
@@ -647,11 +655,31 @@ __device__ __forceinline__ void cover_masks(int shift, int x0, int y0, int x1, i
 // 64 x 64 bit-matrix transpose across a wave: lane k enters with row k, lane t leaves with column t
 // (bit k of the result = bit t of lane k's input).  Six butterfly steps; step j swaps the off-diagonal j x j
 // blocks between lanes l and l ^ j.  ds_swizzle is a lane permutation inside 32-lane halves (no LDS memory).
+// lane ^ J exchange.  J = 1, 2: one DPP quad permutation; J = 4: half-row mirror then quad reversal; J = 8: row mirror
+// then half-row mirror (DPP modifiers ride on VALU moves: full rate, no LDS pipe); J = 16: ds_swizzle, a lane
+// permutation inside 32-lane halves that goes through the LDS pipe (no memory) -- with ten of them per transpose
+// that pipe was what bounded every kernel built on the transpose, hence the DPP forms for the four short strides.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x) {
+#if GS_DPP_TRANSPOSE
+    if (J == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    if (J == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    if (J == 4) {
+        const int t = __builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);             // row_half_mirror: i -> 7 - i
+        return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true);                 // quad_perm [3,2,1,0]
+    }
+    if (J == 8) {
+        const int t = __builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, true);             // row_mirror: i -> 15 - i
+        return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x141, 0xF, 0xF, true);                // row_half_mirror
+    }
+#endif
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (J << 10) | 0x1F);  // lane ^ J
+}
 template <int J>
 __device__ __forceinline__ uint32_t transpose_step(uint32_t x, bool up) {
     constexpr uint32_t MASK = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu
                             : J == 2 ? 0x33333333u : 0x55555555u;
-    const uint32_t p = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (J << 10) | 0x1F);  // lane ^ J
+    const uint32_t p = lane_xor<J>(x);
     return up ? (((p >> J) & MASK) | (x & ~MASK)) : ((x & MASK) | ((p & MASK) << J));
 }
 __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, uint32_t lane) {
@@ -752,6 +780,19 @@ __device__ __forceinline__ void packed_cover_masks(int shift, uint32_t box, uint
     cover_masks<R>(shift, (int)(box & 255u), (int)((box >> 8) & 255u), (int)((box >> 16) & 255u), (int)(box >> 24), m);
 }
 
+// one coverage word (cells 64 r .. 64 r + 63) of a packed box: what cover_masks computes, for a run-time r
+__device__ __forceinline__ uint64_t cover_word(int shift, uint32_t box, int r) {
+    const int x0 = (int)(box & 255u), y0 = (int)((box >> 8) & 255u), x1 = (int)((box >> 16) & 255u), y1 = (int)(box >> 24);
+    const int W = 1 << shift, rows_per_word = 64 >> shift;
+    const uint64_t rowbits = x1 > x0 ? (((1ull << (x1 - x0)) - 1ull) << x0) : 0ull;  // x1 - x0 <= 32 on these grids
+    uint64_t w = 0;
+    for (int yy = 0; yy < rows_per_word; ++yy) {
+        const int y = r * rows_per_word + yy;
+        if (y >= y0 && y < y1) w |= rowbits << (yy * W);
+    }
+    return w;
+}
+
 // Wave w of the block takes chunks 4w .. 4w + 3 (consecutive items): all loads of its four chunks are issued before
 // the first is used, and 8 such blocks are resident per CU -- the kernels are a handful of dependent memory round
 // trips each, so what matters is how many of them are in flight.
@@ -766,35 +807,51 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
     __syncthreads();
     uint32_t n = a.n_items ? *a.n_items : a.n_bound;
     if (n > a.n_bound) n = a.n_bound;
-    uint32_t box[kL1PerWave];
+    // all four items' loads first (independent round trips), then one chunk at a time: the chunk body holds up to 16
+    // inlined transposes and must not be unrolled four times over (the instruction cache is 64 KiB)
+    __shared__ uint32_t s_box[kL1Chunks][WAVE];
+    {
+        uint32_t box[kL1PerWave];
 #pragma unroll
-    for (int j = 0; j < kL1PerWave; ++j)
-        l1_item(a, blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
+        for (int j = 0; j < kL1PerWave; ++j)
+            l1_item(a, blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
+#pragma unroll
+        for (int j = 0; j < kL1PerWave; ++j) s_box[w * kL1PerWave + j][lane] = box[j];
+    }
+    // counting needs no order: every lane adds one to each bin of its box (LDS atomics; typically 1-4 bins, and the rare
+    // screen-filling splat only slows its own wave)
     uint32_t vis = 0;
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < kL1PerWave; ++j) {
-        uint64_t m[R1];
-        packed_cover_masks<R1>(a.g.grid_shift, box[j], m);
-        vis += (uint32_t)__popcll(__ballot(box[j] != 0));
-#pragma unroll
-        for (int r = 0; r < R1; ++r) {
-            if (__builtin_amdgcn_ballot_w64(m[r] != 0) == 0) continue;  // uniform: nobody touches these 64 bins
-            const uint32_t pc = (uint32_t)__popcll(wave_transpose64(m[r], lane));
-            if (pc) atomicAdd(&s_hist[r * 64 + lane], pc);
-        }
+        const uint32_t box = s_box[w * kL1PerWave + j][lane];  // wave-private row: no barrier needed
+        vis += (uint32_t)__popcll(__ballot(box != 0));
+        const uint32_t x0 = box & 255u, y0 = (box >> 8) & 255u, x1 = (box >> 16) & 255u, y1 = box >> 24;
+        for (uint32_t y = y0; y < y1; ++y)
+            for (uint32_t x = x0; x < x1; ++x) atomicAdd(&s_hist[(y << a.g.grid_shift) | x], 1u);
     }
     if (lane == 0 && vis) atomicAdd(&s_vis, vis);
     __syncthreads();
     for (int b = tid; b < NB; b += BLOCK)
         if (bin_on_screen(a.g, b)) a.hist[(size_t)b * a.nblk + blockIdx.x] = s_hist[b];
-    // V on the bin-local path (on the global path the first depth pass counts it)
-    if (tid == 0 && !a.order && s_vis) atomicAdd(&a.counters->visible, s_vis);
+    // V on the bin-local path (on the global path the first depth pass counts it): one more row of the table, summed
+    // by k_l1_scan -- a thousand atomics on one counter would cost more than the rest of this kernel
+    if (tid == 0 && !a.order) a.hist[(size_t)NB * a.nblk + blockIdx.x] = s_vis;
 }
 
 // One workgroup per bin: exclusive prefix of the bin's row of block counts (in place), row total -> bin_count.
 __global__ __launch_bounds__(BLOCK) void k_l1_scan(L1Args a) {
     __shared__ uint32_t scratch[8];
     const uint32_t bin = blockIdx.x;
+    const uint32_t nb = 1u << (2 * a.g.grid_shift);
+    if (bin == nb) {  // the row of per-block visible counts (bin-local path): V
+        if (a.order) return;
+        uint32_t sum = 0;
+        for (uint32_t i = threadIdx.x; i < a.nblk; i += BLOCK) sum += a.hist[(size_t)nb * a.nblk + i];
+        uint32_t total;
+        block_excl_scan<BLOCK>(sum, scratch, &total);
+        if (threadIdx.x == 0) a.counters->visible = total;
+        return;
+    }
     if (!bin_on_screen(a.g, bin)) {
         if (threadIdx.x == 0) a.bin_count[bin] = 0;
         return;
@@ -852,21 +909,34 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
     }
     uint32_t n = a.n_items ? *a.n_items : a.n_bound;
     if (n > a.n_bound) n = a.n_bound;
-    uint32_t box[kL1PerWave];
+    __shared__ uint32_t s_box[kL1Chunks][WAVE];
+    {   // all four items' loads first (independent round trips)
+        uint32_t box[kL1PerWave], gid[kL1PerWave];
 #pragma unroll
-    for (int j = 0; j < kL1PerWave; ++j) {
-        const int ch = w * kL1PerWave + j;
-        s_ids[ch][lane] = l1_item(a, blockIdx.x * kL1Items + ch * WAVE + lane, n, box[j]);
+        for (int j = 0; j < kL1PerWave; ++j)
+            gid[j] = l1_item(a, blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
+#pragma unroll
+        for (int j = 0; j < kL1PerWave; ++j) {
+            s_ids[w * kL1PerWave + j][lane] = gid[j];
+            s_box[w * kL1PerWave + j][lane] = box[j];
+        }
     }
-#pragma unroll
-    for (int j = 0; j < kL1PerWave; ++j) {
-        const int ch = w * kL1PerWave + j;
-        uint64_t m[R1];
-        packed_cover_masks<R1>(a.g.grid_shift, box[j], m);
-#pragma unroll
-        for (int r = 0; r < R1; ++r) {
-            const uint64_t col = __builtin_amdgcn_ballot_w64(m[r] != 0) != 0 ? wave_transpose64(m[r], lane) : 0ull;
-            s_cnt[ch][r * 64 + lane] = (uint16_t)__popcll(col);
+    // per chunk and bin: how many of the chunk's items touch the bin.  Counting needs no order: LDS atomics on the
+    // 16-bit counters, two to a word (a chunk contributes at most 64 to a counter: no carry between the halves)
+    {
+        uint32_t* words = reinterpret_cast<uint32_t*>(&s_cnt[0][0]);
+        for (int k = tid; k < kL1Chunks * NB / 2; k += BLOCK) words[k] = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < kL1PerWave; ++j) {
+            const int ch = w * kL1PerWave + j;
+            const uint32_t box = s_box[ch][lane];
+            const uint32_t x0 = box & 255u, y0 = (box >> 8) & 255u, x1 = (box >> 16) & 255u, y1 = box >> 24;
+            for (uint32_t y = y0; y < y1; ++y)
+                for (uint32_t x = x0; x < x1; ++x) {
+                    const uint32_t e = (uint32_t)ch * NB + ((y << a.g.grid_shift) | x);
+                    atomicAdd(&words[e >> 1], 1u << (16u * (e & 1u)));
+                }
         }
     }
     __syncthreads();
@@ -882,16 +952,71 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
     __syncthreads();
     // raw buffer over the candidate list: byte offsets >= 4 * capacity are dropped by the hardware bounds check
     const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.cand, 0, a.capacity * 4u, 0x27000);
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < kL1PerWave; ++j) {
         const int ch = w * kL1PerWave + j;
+#if GS_L1_WORDLOOP
+        const uint32_t box = s_box[ch][lane];
+#pragma unroll 1
+        for (int r = 0; r < R1; ++r) {
+            const uint64_t mr = cover_word(a.g.grid_shift, box, r);
+            if (__builtin_amdgcn_ballot_w64(mr != 0) == 0) continue;
+            walk_column(wave_transpose64(mr, lane), s_start[r * 64 + lane] + s_cnt[ch][r * 64 + lane], out, s_ids[ch]);
+        }
+#else
         uint64_t m[R1];
-        packed_cover_masks<R1>(a.g.grid_shift, box[j], m);
+        packed_cover_masks<R1>(a.g.grid_shift, s_box[ch][lane], m);
 #pragma unroll
         for (int r = 0; r < R1; ++r) {
             if (__builtin_amdgcn_ballot_w64(m[r] != 0) == 0) continue;
             walk_column(wave_transpose64(m[r], lane), s_start[r * 64 + lane] + s_cnt[ch][r * 64 + lane], out, s_ids[ch]);
         }
+#endif
+    }
+}
+
+// Bin-local path: the order of a bin's candidates does not matter (k_bin_fast orders them by (depth bits, id), a total
+// order), so a block's items take their slots in its run of each bin's list with LDS atomics -- no ranking at all.
+template <int R1>
+__global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
+    constexpr int NB = 64 * R1;
+    __shared__ uint32_t s_cur[NB];  // next free slot of this block's run in each bin's list
+    __shared__ uint32_t scratch[8];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    {   // bin offsets = exclusive scan of the bin totals (<= 1024 values: every block redoes it, no extra launch)
+        uint32_t c[NB / BLOCK], sum = 0;
+#pragma unroll
+        for (int k = 0; k < NB / BLOCK; ++k) {
+            c[k] = a.bin_count[tid * (NB / BLOCK) + k];
+            sum += c[k];
+        }
+        uint32_t total;
+        uint32_t off = block_excl_scan<BLOCK>(sum, scratch, &total);
+#pragma unroll
+        for (int k = 0; k < NB / BLOCK; ++k) {
+            const uint32_t b = tid * (NB / BLOCK) + k;
+            s_cur[b] = off + (bin_on_screen(a.g, b) ? a.hist[(size_t)b * a.nblk + blockIdx.x] : 0u);
+            off += c[k];
+            if (blockIdx.x == 0 && c[k]) atomicMax(&a.counters->max_bin, c[k]);  // the fullest bin
+        }
+        if (blockIdx.x == 0 && tid == 0) {  // E1, candidate overflow
+            a.counters->bin_entries = total;
+            if (total > a.capacity) atomicOr(&a.counters->overflow, 1u);
+        }
+    }
+    uint32_t box[kL1PerWave], gid[kL1PerWave];
+#pragma unroll
+    for (int j = 0; j < kL1PerWave; ++j)  // all four items' loads first (independent round trips)
+        gid[j] = l1_item(a, blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane, a.n_bound, box[j]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kL1PerWave; ++j) {
+        const uint32_t x0 = box[j] & 255u, y0 = (box[j] >> 8) & 255u, x1 = (box[j] >> 16) & 255u, y1 = box[j] >> 24;
+        for (uint32_t y = y0; y < y1; ++y)
+            for (uint32_t x = x0; x < x1; ++x) {
+                const uint32_t pos = atomicAdd(&s_cur[(y << a.g.grid_shift) | x], 1u);
+                if (pos < a.capacity) a.cand[pos] = gid[j];
+            }
     }
 }
 
@@ -929,6 +1054,14 @@ __device__ __forceinline__ uint32_t bin_local_box(const BinGrid& g, uint32_t bin
 
 constexpr int kBuildSlots = 16;  // chunks per fill round (one or four per wave)
 
+#ifdef GS_BUILD_TIMING
+// debug instrumentation (separate build, never the shipped library): per bin, the constant-rate clock at phase ends
+__device__ unsigned long long g_build_t[1024][8];
+#define BUILD_T(i) do { if (threadIdx.x == 0) g_build_t[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define BUILD_T(i) do { } while (0)
+#endif
+
 template <int R2, int THREADS, bool SORT>
 struct BuildLayout {
     static constexpr int NW = THREADS / WAVE;
@@ -961,6 +1094,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const uint32_t bin = blockIdx.x;
     if (!bin_on_screen(a.g, bin)) return;  // padding of the bin grid: no tiles
+    BUILD_T(0);
     uint32_t c, off;
     {   // this bin's count and offset (exclusive scan over the <= 1024 bins of the padded grid)
         const uint32_t nb = 1u << (2 * a.g.grid_shift);
@@ -981,13 +1115,32 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
         if (tid == 0) atomicOr(&a.counters->overflow, 2u);
         c = 0;
     }
+    BUILD_T(1);
     if (SORT && c != 0) {
-        for (uint32_t e = tid; e < c; e += THREADS) {
-            const uint32_t g = a.cand[off + e];
-            s_id[e] = g;
-            s_key[e] = __float_as_uint(a.depth[g]);
-        }
         constexpr int kRounds = 16;  // MAXC / THREADS
+        {   // ids, then their depths: all of a thread's loads of one kind are in flight together (two round trips in all,
+            // where a loop over the elements would chain two per element)
+            uint32_t g[kRounds], k[kRounds];
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const uint32_t e = r * THREADS + tid;
+                g[r] = e < c ? a.cand[off + e] : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const uint32_t e = r * THREADS + tid;
+                k[r] = e < c ? __float_as_uint(a.depth[g[r]]) : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const uint32_t e = r * THREADS + tid;
+                if (e < c) {
+                    s_id[e] = g[r];
+                    s_key[e] = k[r];
+                }
+            }
+        }
+        BUILD_T(2);
         const uint64_t lt_mask = (1ull << lane) - 1ull;
         // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
         const int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= kRounds
@@ -1068,10 +1221,22 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
             }
             __syncthreads();  // the cursors in s_wcnt are re-zeroed at the top of the next pass
         }
+        BUILD_T(3);
         if (L::CACHE_BOX) {  // the order is final: the key area now holds every candidate's bin-local tile box
-            for (uint32_t e = tid; e < c; e += THREADS) s_key[e] = bin_local_box(a.g, bin, a.aabb[s_id[e]]);
+            ushort4 box[kRounds];
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {  // all gathers in flight together
+                const uint32_t e = r * THREADS + tid;
+                box[r] = e < c ? a.aabb[s_id[e]] : make_ushort4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const uint32_t e = r * THREADS + tid;
+                if (e < c) s_key[e] = bin_local_box(a.g, bin, box[r]);
+            }
         }
     }
+    BUILD_T(4);
     // ---- per-tile counts (the tables live behind the ids, or in the key area when the boxes are not cached)
     for (int t = tid; t < SS; t += THREADS) t_cnt[t] = 0;
     __syncthreads();
@@ -1106,6 +1271,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
             if (acc[r]) atomicAdd(&t_cnt[r * 64 + lane], acc[r]);
     }
     __syncthreads();
+    BUILD_T(5);
     // ---- tile ranges: a segment of the list buffer for the bin (tiles consecutive inside it)
     {
         uint32_t v[(SS + THREADS - 1) / THREADS], sum = 0;
@@ -1146,6 +1312,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
         }
     }
     __syncthreads();
+    BUILD_T(6);
     // ---- fill, 16 chunks per round (PER per wave, consecutive) so that the lists keep the candidates' order
     const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, a.capacity * 4u, 0x27000);
     int par = 0;
@@ -1184,7 +1351,372 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
             }
         }
     }
+    BUILD_T(7);
 }
+
+#ifdef GS_BUILD_TIMING
+extern "C" int gs_debug_build_timing(unsigned long long* out /* [1024][8] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_build_t), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------
+// Level 2, bin-local path, bins of 4 x 4 or 8 x 8 tiles (every resolution up to 4096 x 4096 tiles... i.e. 8K): one
+// 1024-thread workgroup per bin, everything in LDS.
+//   1. the bin's candidates (any order) and their depth bits -> LDS;
+//   2. four stable 8-bit LSD passes on the depth bits (ballot-matched ranks, as above);
+//   3. ties: candidates of equal depth must follow each other by Gaussian id (what the reference's stable sort of
+//      (tile, depth) keys over index-ordered input gives).  Equal keys are adjacent now; every element of a run of
+//      equal keys counts the smaller ids of its run and moves there.  Runs are short (two or three) unless the scene
+//      is degenerate; a run longer than 64 sends the whole bin through id passes followed by the depth passes again;
+//   4. per candidate: its tile box inside the bin (16 bits) and, with LDS atomics, how many candidates of each
+//      64-candidate chunk cover each tile; prefix over the chunks per tile; tile totals -> a segment of the list
+//      buffer (one atomic add), the tile ranges;
+//   5. fill: a wave takes a chunk; for each tile of the bin, a ballot of the lanes whose box covers it ranks them in
+//      list order, and they store their ids at  tile start + chunk prefix + rank  -- consecutive addresses.
+// ROUNDS = candidates per thread: 4, 8 or 16 (4096 / 8192 / 16384 per bin; 48 / 72 / 136 KiB of LDS).
+// ---------------------------------------------------------------------------------------
+template <int ROUNDS>
+struct FastLayout {
+    static constexpr int THREADS = 1024, NW = THREADS / WAVE, MAXC = THREADS * ROUNDS;
+    static constexpr int WCNT_WORDS = NW * 256 / 2;                       // u16 [16][256]
+    static constexpr int MISC_WORDS = 64 + 64 + NW * 64;                  // t_cnt, t_cur, s_seg
+    static constexpr int TAIL = WCNT_WORDS > MISC_WORDS ? WCNT_WORDS : MISC_WORDS;
+    static constexpr int WORDS = 2 * MAXC + TAIL;
+};
+
+template <int ROUNDS>
+__device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
+    using L = FastLayout<ROUNDS>;
+    constexpr int THREADS = L::THREADS, NW = L::NW, MAXC = L::MAXC;
+    extern __shared__ uint32_t smem[];
+    uint32_t* const s_key = smem;
+    uint32_t* const s_id = smem + MAXC;
+    uint16_t (*const s_wcnt)[256] = reinterpret_cast<uint16_t(*)[256]>(smem + 2 * MAXC);
+    // once the order is final: the key area holds the 16-bit boxes and the chunk table, the counter area the tile tables
+    uint16_t* const s_box = reinterpret_cast<uint16_t*>(smem);                                   // [MAXC]
+    uint16_t (*const s_tbl)[64] = reinterpret_cast<uint16_t(*)[64]>(smem + MAXC / 2);           // [MAXC / 64][64]
+    uint32_t* const t_cnt = smem + 2 * MAXC;                                                     // [64]
+    uint32_t* const t_cur = t_cnt + 64;                                                          // [64]
+    uint32_t (*const s_seg)[64] = reinterpret_cast<uint32_t(*)[64]>(t_cnt + 128);                // [16][64]
+    __shared__ uint32_t scratch[NW];
+    __shared__ uint32_t s_seg0, s_flag;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const uint32_t bin = blockIdx.x;
+    if (!bin_on_screen(a.g, bin)) return;  // padding of the bin grid: no tiles
+    BUILD_T(0);
+    uint32_t c, off;
+    {   // this bin's count and offset (the padded grid has <= 1024 = THREADS bins)
+        const uint32_t nb = 1u << (2 * a.g.grid_shift);
+        const uint32_t v = (uint32_t)tid < nb ? a.bin_count[tid] : 0u;
+        uint32_t tb, tm;
+        block_excl_scan<THREADS>((uint32_t)tid < bin ? v : 0u, scratch, &tb);
+        block_excl_scan<THREADS>((uint32_t)tid == bin ? v : 0u, scratch, &tm);
+        c = tm;
+        off = tb;
+    }
+    if ((uint64_t)off + c > a.capacity) c = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
+    if (c > (uint32_t)MAXC) {
+        if (tid == 0) atomicOr(&a.counters->overflow, 2u);
+        c = 0;
+    }
+    if (tid == 0) s_flag = 0;
+    BUILD_T(1);
+    const int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= ROUNDS
+    {   // ids, then their depths: all of a thread's loads of one kind are in flight together
+        uint32_t g[ROUNDS], k[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            g[r] = e < c ? a.cand[off + e] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            k[r] = e < c ? __float_as_uint(a.depth[g[r]]) : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            if (e < c) {
+                s_id[e] = g[r];
+                s_key[e] = k[r];
+            }
+        }
+    }
+    BUILD_T(2);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // One stable 8-bit LSD pass in place.  code 0..3: byte `code` of the depth bits; 4..7: byte `code - 4` of the id.
+    // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
+    const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
+    auto radix_pass = [&](int code) {
+        const int shift = (code & 3) * 8;
+        const bool by_id = code >= 4;
+        for (int k = tid; k < NW * 256 / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0;
+        __syncthreads();  // also orders the previous pass's (or the load's) LDS writes before this pass's reads
+        uint32_t key[ROUNDS], id[ROUNDS], rank[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            key[r] = 0;
+            id[r] = 0;
+            rank[r] = 0;
+            if (r < rounds) {
+                const uint32_t e = wbase + r * WAVE + lane;
+                const bool ok = e < c;
+                if (ok) {
+                    key[r] = s_key[e];
+                    id[r] = s_id[e];
+                }
+                const uint32_t d = ((by_id ? id[r] : key[r]) >> shift) & 255u;
+                // lanes holding a valid element with my digit: AND over the bits of (ballot(bit) XNOR my bit)
+                const uint64_t okm = __ballot(ok);
+                uint32_t mlo = (uint32_t)okm, mhi = (uint32_t)(okm >> 32);
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) {
+                    const uint32_t mine = (d >> bit) & 1u;
+                    const uint64_t b = __builtin_amdgcn_ballot_w64(mine != 0);
+                    const uint32_t splat = 0u - mine;
+                    mlo &= ~((uint32_t)b ^ splat);
+                    mhi &= ~((uint32_t)(b >> 32) ^ splat);
+                }
+                const uint64_t m = ((uint64_t)mhi << 32) | mlo;
+                uint32_t old = 0;
+                const int leader = m ? (__ffsll((unsigned long long)m) - 1) : 0;
+                if (ok && lane == leader) {
+                    old = s_wcnt[w][d];
+                    s_wcnt[w][d] = (uint16_t)(old + (uint32_t)__popcll(m));
+                }
+                old = __shfl(old, leader, WAVE);
+                rank[r] = old + (uint32_t)__popcll(m & lt_mask);
+            }
+        }
+        __syncthreads();
+        {   // per digit: prefix over the waves, then exclusive scan over the digits -> per-wave write cursors
+            uint32_t cw[NW], cnt = 0;
+            if (tid < 256) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    cw[k] = s_wcnt[k][tid];
+                    cnt += cw[k];
+                }
+            }
+            uint32_t all;
+            uint32_t excl = block_excl_scan<THREADS>(cnt, scratch, &all);
+            if (tid < 256) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    s_wcnt[k][tid] = (uint16_t)excl;
+                    excl += cw[k];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (r < rounds) {
+                const uint32_t e = wbase + r * WAVE + lane;
+                if (e < c) {
+                    const uint32_t d = ((by_id ? id[r] : key[r]) >> shift) & 255u;
+                    const uint32_t pos = (uint32_t)s_wcnt[w][d] + rank[r];
+                    s_key[pos] = key[r];
+                    s_id[pos] = id[r];
+                }
+            }
+        }
+        __syncthreads();
+    };
+    if (c != 0) {
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) radix_pass(pass);
+        // ---- ties by id.  Runs of equal keys are adjacent; look at most 64 to either side.
+        uint32_t mv_pos[ROUNDS], mv_id[ROUNDS];
+        bool too_long = false;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            mv_pos[r] = 0xFFFFFFFFu;
+            mv_id[r] = 0;
+            const uint32_t e = r * THREADS + tid;
+            if (r < rounds && e < c) {
+                const uint32_t k = s_key[e];
+                const bool tie_lo = e > 0 && s_key[e - 1] == k, tie_hi = e + 1 < c && s_key[e + 1] == k;
+                if (tie_lo || tie_hi) {
+                    uint32_t lo = e, hi = e;
+                    while (lo > 0 && e - lo < 64 && s_key[lo - 1] == k) --lo;
+                    while (hi + 1 < c && hi - e < 64 && s_key[hi + 1] == k) ++hi;
+                    if ((lo > 0 && s_key[lo - 1] == k) || (hi + 1 < c && s_key[hi + 1] == k)) too_long = true;
+                    const uint32_t me = s_id[e];
+                    uint32_t smaller = 0;
+                    for (uint32_t j = lo; j <= hi; ++j) smaller += s_id[j] < me ? 1u : 0u;
+                    mv_pos[r] = lo + smaller;
+                    mv_id[r] = me;
+                }
+            }
+        }
+        if (too_long) s_flag = 1;
+        __syncthreads();  // every read of the old order is done
+        const bool redo = s_flag != 0;
+        if (!redo) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r)
+                if (mv_pos[r] != 0xFFFFFFFFu) s_id[mv_pos[r]] = mv_id[r];
+        }
+        __syncthreads();
+        if (redo) {  // a long run of equal depths: order by id first (four bytes cover any id), then by depth again
+#pragma unroll 1
+            for (int pass = 4; pass < 8; ++pass) radix_pass(pass);
+#pragma unroll 1
+            for (int pass = 0; pass < 4; ++pass) radix_pass(pass);
+        }
+    }
+    BUILD_T(3);
+    // ---- the candidates' tile boxes inside the bin, and the (chunk, tile) counts
+    const uint32_t nch = (c + WAVE - 1) / WAVE;
+    const int S = 1 << a.g.bin_shift;
+    {
+        ushort4 box[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {  // all gathers in flight together
+            const uint32_t e = r * THREADS + tid;
+            box[r] = e < c ? a.aabb[s_id[e]] : make_ushort4(0, 0, 0, 0);
+        }
+        __syncthreads();  // the keys are dead from here on: their area becomes boxes + chunk table
+        for (uint32_t k = tid; k < (uint32_t)MAXC / 2; k += THREADS) smem[MAXC / 2 + k] = 0;  // the table
+        if (tid < 64) t_cnt[tid] = 0;
+        __syncthreads();
+        uint32_t* const tbl_words = smem + MAXC / 2;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            if (e < c) {
+                const uint32_t pb = bin_local_box(a.g, bin, box[r]);
+                const uint32_t lx0 = pb & 255u, ly0 = (pb >> 8) & 255u, lx1 = (pb >> 16) & 255u, ly1 = pb >> 24;
+                s_box[e] = (uint16_t)(lx0 | (ly0 << 4) | ((lx1 - 1u) << 8) | ((ly1 - 1u) << 12));  // inclusive upper bounds
+                if (S == 4) {  // 16 tiles: a handful of LDS atomics per candidate (16-bit counters, two to a word; <= 64 each)
+                    const uint32_t row = (e >> 6) * 64u;
+                    for (uint32_t y = ly0; y < ly1; ++y)
+                        for (uint32_t x = lx0; x < lx1; ++x) {
+                            const uint32_t idx = row + (y << 2) + x;
+                            atomicAdd(&tbl_words[idx >> 1], 1u << (16u * (idx & 1u)));
+                        }
+                }
+            }
+        }
+        if (S != 4) {  // 64 tiles: one bit-matrix transpose per chunk hands lane t the column of tile t
+            __syncthreads();
+            for (uint32_t ch = w; ch < nch; ch += NW) {
+                const uint32_t e = ch * WAVE + lane;
+                const uint32_t pb = e < c ? (uint32_t)s_box[e] : 0xFFFFu;  // 0xFFFF: x0 = 15 > x1: covers nothing
+                uint64_t m[1];
+                cover_masks<1>(3, (int)(pb & 15u), (int)((pb >> 4) & 15u), (int)((pb >> 8) & 15u) + 1, (int)(pb >> 12) + 1, m);
+                if (e >= c) m[0] = 0;
+                s_tbl[ch][lane] = (uint16_t)__popcll(wave_transpose64(m[0], lane));
+            }
+        }
+    }
+    __syncthreads();
+    BUILD_T(4);
+    // ---- per tile: exclusive prefix of the chunk counts (16 segments of chunks per tile), tile total
+    {
+        const int t = tid & 63, g = tid >> 6;
+        const uint32_t per = (nch + NW - 1) / NW;
+        const uint32_t q0 = min(nch, (uint32_t)g * per), q1 = min(nch, q0 + per);
+        uint32_t sum = 0;
+        for (uint32_t q = q0; q < q1; ++q) sum += s_tbl[q][t];
+        s_seg[g][t] = sum;
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const uint32_t v = s_seg[k][tid];
+                s_seg[k][tid] = run;
+                run += v;
+            }
+            t_cnt[tid] = run;
+        }
+        __syncthreads();
+        uint32_t run = s_seg[g][t];
+        for (uint32_t q = q0; q < q1; ++q) {
+            const uint32_t v = s_tbl[q][t];
+            s_tbl[q][t] = (uint16_t)run;  // a tile's list in a bin is at most MAXC long: 16 bits
+            run += v;
+        }
+    }
+    __syncthreads();
+    BUILD_T(5);
+    // ---- tile ranges: a segment of the list buffer for the bin (tiles consecutive inside it)
+    {
+        const uint32_t v = tid < 64 ? t_cnt[tid] : 0u;
+        uint32_t d_bin;
+        const uint32_t excl = block_excl_scan<THREADS>(v, scratch, &d_bin);
+        if (tid == 0) {
+            const uint32_t seg = d_bin ? atomicAdd(&a.counters->instances, d_bin) : 0u;
+            s_seg0 = seg;
+            if ((uint64_t)seg + d_bin > a.capacity) atomicOr(&a.counters->overflow, 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t ox = (bin & ((1u << a.g.grid_shift) - 1u)) << a.g.bin_shift, oy = (bin >> a.g.grid_shift) << a.g.bin_shift;
+            const uint32_t lx = (uint32_t)tid & (uint32_t)(S - 1), ly = (uint32_t)tid >> a.g.bin_shift;
+            const uint32_t x = ox + lx, y = oy + ly;
+            // saturating: an overflowing frame is re-run, but its ranges must stay inside the list
+            const uint64_t start64 = (uint64_t)s_seg0 + excl;
+            const uint32_t start = start64 > a.capacity ? a.capacity : (uint32_t)start64;
+            const uint32_t end = start64 + v > a.capacity ? a.capacity : (uint32_t)(start64 + v);
+            if (ly < (uint32_t)S && x < a.g.tiles_x && y < a.g.tiles_y) {
+                // absent tiles stay (0, 0) like the reference's zero-filled tileBoundaryBuffer
+                a.ranges[2 * (y * a.g.tiles_x + x)] = v ? start : 0u;
+                a.ranges[2 * (y * a.g.tiles_x + x) + 1] = v ? end : 0u;
+            }
+            t_cur[tid] = start;
+        }
+    }
+    __syncthreads();
+    BUILD_T(6);
+    // ---- fill.  Chunks are independent now: the table holds where each chunk's run starts in every tile's list.
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, a.capacity * 4u, 0x27000);
+    for (uint32_t ch = w; ch < nch; ch += NW) {
+        const uint32_t e = ch * WAVE + lane;
+        const bool valid = e < c;
+        const uint32_t id = valid ? s_id[e] : 0u;
+        const uint32_t pb = valid ? (uint32_t)s_box[e] : 0u;
+        const int lx0 = (int)(pb & 15u), ly0 = (int)((pb >> 4) & 15u), lx1 = (int)((pb >> 8) & 15u), ly1 = (int)(pb >> 12);
+        // lane t: where this chunk's run starts in tile t's list
+        const uint32_t base = t_cur[lane] + (uint32_t)s_tbl[ch][lane];
+        if (S == 4) {
+            // 16 tiles: for each, the ballot of the covering lanes ranks them in list order and they store their ids at
+            // consecutive addresses
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int tx = t & 3, ty = t >> 2;
+                const bool covered = valid && tx >= lx0 && tx <= lx1 && ty >= ly0 && ty <= ly1;
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(covered);
+                if (bal == 0) continue;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)base, t) + rank;
+                __builtin_amdgcn_raw_buffer_store_b32(id, out, covered ? pos * 4u : 0xFFFFFFFFu, 0, 0);
+            }
+        } else {
+            // 64 tiles: transpose, then every lane walks its tile's column (up to four ids per store)
+            uint64_t m[1];
+            cover_masks<1>(3, lx0, ly0, lx1 + 1, ly1 + 1, m);
+            if (!valid) m[0] = 0;
+            walk_column(wave_transpose64(m[0], lane), base, out, s_id + ch * WAVE);
+        }
+    }
+    BUILD_T(7);
+}
+// 8 waves per SIMD for the two smaller sizes, i.e. two workgroups per CU: needs <= 64 VGPRs and <= 80 SGPRs (a SIMD has
+// 800 SGPRs, allocated in sixteens plus sixteen per wave); the attribute wants a literal, hence three kernels
+template <int ROUNDS> __global__ void k_bin_fast(BuildArgs a);
+template <> __global__ __launch_bounds__(1024, 8) __attribute__((amdgpu_num_sgpr(80))) void k_bin_fast<4>(BuildArgs a) {
+    bin_fast_body<4>(a);
+}
+template <> __global__ __launch_bounds__(1024, 8) __attribute__((amdgpu_num_sgpr(80))) void k_bin_fast<8>(BuildArgs a) {
+    bin_fast_body<8>(a);
+}
+template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<16>(BuildArgs a) { bin_fast_body<16>(a); }
 
 static L1Args l1_args(const BinLaunch& b) {
     L1Args a;
@@ -1210,14 +1742,19 @@ void launch_bin_level1_count(const BinLaunch& b, hipStream_t s) {
     if (a.nblk == 0) return;
     if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_hist<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
     else hipLaunchKernelGGL(k_l1_hist<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
-    hipLaunchKernelGGL(k_l1_scan, dim3(1u << (2 * b.grid_shift)), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_l1_scan, dim3((1u << (2 * b.grid_shift)) + 1u), dim3(BLOCK), 0, s, a);
 }
 
-void launch_bin_level1_scatter(const BinLaunch& b, hipStream_t s) {
+void launch_bin_level1_scatter(const BinLaunch& b, bool any_order, hipStream_t s) {
     const L1Args a = l1_args(b);
     if (a.nblk == 0) return;
-    if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_scatter<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
-    else hipLaunchKernelGGL(k_l1_scatter<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+    if (any_order) {
+        if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_scatter_any_order<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(k_l1_scatter_any_order<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+    } else {
+        if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_scatter<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(k_l1_scatter<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+    }
 }
 
 template <int R2, int THREADS, bool SORT>
@@ -1226,25 +1763,28 @@ static hipError_t build_prepare() {  // > 64 KiB of dynamic LDS needs the attrib
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(BuildLayout<R2, THREADS, SORT>::WORDS * sizeof(uint32_t)));
 }
+template <int ROUNDS>
+static hipError_t fast_prepare() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_fast<ROUNDS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(FastLayout<ROUNDS>::WORDS * sizeof(uint32_t)));
+}
 hipError_t bin_prepare_device() {  // once per device (gs_renderer::init)
-    hipError_t e = build_prepare<1, 1024, true>();
-    if (e == hipSuccess) e = build_prepare<4, 1024, true>();
+    hipError_t e = build_prepare<4, 1024, true>();
     if (e == hipSuccess) e = build_prepare<16, 1024, true>();
-    if (e == hipSuccess) e = build_prepare<16, 256, true>();
+    if (e == hipSuccess) e = fast_prepare<8>();
+    if (e == hipSuccess) e = fast_prepare<16>();
     return e;
 }
 
 template <int R2>
-static void launch_build(const BuildArgs& a, int variant, uint32_t bins, hipStream_t s) {
-    constexpr size_t lds0 = BuildLayout<R2, 256, true>::WORDS * sizeof(uint32_t);
+static void launch_build(const BuildArgs& a, bool sort, uint32_t bins, hipStream_t s) {
     constexpr size_t lds1 = BuildLayout<R2, 1024, true>::WORDS * sizeof(uint32_t);
     constexpr size_t lds2 = BuildLayout<R2, 1024, false>::WORDS * sizeof(uint32_t);
-    if (variant == 0) hipLaunchKernelGGL((k_bin_build<R2, 256, true>), dim3(bins), dim3(256), lds0, s, a);
-    else if (variant == 1) hipLaunchKernelGGL((k_bin_build<R2, 1024, true>), dim3(bins), dim3(1024), lds1, s, a);
+    if (sort) hipLaunchKernelGGL((k_bin_build<R2, 1024, true>), dim3(bins), dim3(1024), lds1, s, a);
     else hipLaunchKernelGGL((k_bin_build<R2, 1024, false>), dim3(bins), dim3(1024), lds2, s, a);
 }
 
-void launch_bin_level2(const BinLaunch& b, int variant, hipStream_t s) {
+void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
     BuildArgs a;
     a.g = BinGrid{b.tiles_x, b.tiles_y, b.bins_x, b.bins_y, b.bin_shift, b.grid_shift};
     a.cand = b.cand;
@@ -1256,9 +1796,18 @@ void launch_bin_level2(const BinLaunch& b, int variant, hipStream_t s) {
     a.counters = b.counters;
     a.capacity = b.capacity;
     const uint32_t bins = 1u << (2 * b.grid_shift);
-    if (b.bin_shift <= 3) launch_build<1>(a, variant, bins, s);
-    else if (b.bin_shift == 4) launch_build<4>(a, variant, bins, s);
-    else launch_build<16>(a, variant, bins, s);
+    const bool sort = level < 3;
+    if (sort && b.bin_shift <= 3) {  // bins of 4 x 4 or 8 x 8 tiles: the all-in-LDS kernel, sized by the level
+        if (level == 0) hipLaunchKernelGGL(k_bin_fast<4>, dim3(bins), dim3(1024), FastLayout<4>::WORDS * sizeof(uint32_t), s, a);
+        else if (level == 1) hipLaunchKernelGGL(k_bin_fast<8>, dim3(bins), dim3(1024), FastLayout<8>::WORDS * sizeof(uint32_t), s, a);
+        else hipLaunchKernelGGL(k_bin_fast<16>, dim3(bins), dim3(1024), FastLayout<16>::WORDS * sizeof(uint32_t), s, a);
+    } else if (b.bin_shift <= 3) {
+        launch_build<1>(a, sort, bins, s);
+    } else if (b.bin_shift == 4) {
+        launch_build<4>(a, sort, bins, s);
+    } else {
+        launch_build<16>(a, sort, bins, s);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1356,7 +1905,13 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                                                  const float4* __restrict__ uv_rg, const float* __restrict__ bch,
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
                                                  float4* __restrict__ rgba, uchar4* __restrict__ bgra,
-                                                 const Counters* __restrict__ counters, Counters* host_counters) {
+                                                 const Counters* __restrict__ counters, Counters* host_counters,
+                                                 const FrameParams* __restrict__ fp) {
+    if (fp) {  // graph replay: this frame's targets come from the parameter block
+        rgba = reinterpret_cast<float4*>(fp->rgba);
+        bgra = reinterpret_cast<uchar4*>(fp->bgra);
+        host_counters = fp->host_counters;
+    }
     // wave-private slabs (no cross-wave sharing, no barriers), three planes of 64 float4 per wave: {c00 c01 c11 o} {u v r g} {b, pmin, -, -}.  Plane-major keeps the staging
     // ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets serve the reads
     __shared__ float4 s_rec[4][3][WAVE];
@@ -1492,17 +2047,17 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
-                  Counters* host_counters, bool hw_exp, hipStream_t s) {
+                  Counters* host_counters, bool hw_exp, const FrameParams* fp, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
     if (hw_exp)
         hipLaunchKernelGGL(k_blend<true>, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                            sorted_gid, tile_order, av.conic_op, av.uv_rg, av.b, width, height, tx,
-                           reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters);
+                           reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp);
     else
         hipLaunchKernelGGL(k_blend<false>, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                            sorted_gid, tile_order, av.conic_op, av.uv_rg, av.b, width, height, tx,
-                           reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters);
+                           reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp);
 }
 
 #ifdef GS_BLEND_STATS

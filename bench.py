@@ -50,14 +50,11 @@ def workload_name(n, w, h, world):
     return base + " (not a BASELINE config)"
 
 
-def bin_grid(w, h, min_shift=2):
-    """The bin grid gs_renderer::bin_geometry picks: bins of S x S tiles, S the smallest power of two >= 4 that keeps
-    the grid within 32 x 32.  Returns (S, bins)."""
+def bin_count(w, h, bin_tiles):
+    """Bins of bin_tiles x bin_tiles tiles on the screen (gs_frame_stats.bin_tiles: 8 by default, 4 when refined, larger
+    only beyond 4K to keep the grid within 32 x 32)."""
     tx, ty = (w + 15) // 16, (h + 15) // 16
-    s = min_shift
-    while ((tx - 1) >> s) + 1 > 32 or ((ty - 1) >> s) + 1 > 32:
-        s += 1
-    return 1 << s, (((tx - 1) >> s) + 1) * (((ty - 1) >> s) + 1)
+    return ((tx + bin_tiles - 1) // bin_tiles) * ((ty + bin_tiles - 1) // bin_tiles)
 
 
 def algorithmic_bytes(n, v, d, e1, t, p, bins, bin_local=True):
@@ -93,6 +90,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bgra8", action="store_true", help="also write the B8G8R8A8_UNORM image")
+    ap.add_argument("--hw-exp", action="store_true", help="blend with the hardware's v_exp_f32 (gs_set_exp_mode(1))")
+    ap.add_argument("--sh16", action="store_true", help="opt-in binary16 SH storage (gs_scene_quantize_sh)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -132,8 +131,12 @@ def main():
     pkg.dist.broadcast_blob(blob, src=0)  # RCCL over xGMI; no-op at world == 1
     torch.cuda.synchronize()
     scene = pkg.Scene.from_device_blob(blob.data_ptr(), n, device=local_rank, keepalive=blob)
+    if args.sh16:
+        scene.quantize_sh()
     rend = pkg.Renderer(scene)
     rend.set_frames_in_flight(args.frames_in_flight)
+    if args.hw_exp:
+        rend.set_exp_mode(1)
 
     cam = pkg.make_camera(rotation=pkg.dist.pose_quaternion(rank))  # pose k = default camera yawed k*5 deg
     u = pkg.camera_uniforms(cam, w, h)
@@ -199,7 +202,8 @@ def main():
     if rank == 0:
         fps = world * args.steps / elapsed
         T = ((w + 15) // 16) * ((h + 15) // 16)
-        bin_edge, bins = bin_grid(w, h, int(os.environ.get("GS_BIN_SHIFT", 2)))
+        bin_edge = int(st.bin_tiles)
+        bins = bin_count(w, h, bin_edge)
         nbytes = algorithmic_bytes(st.num_gaussians, st.num_visible, st.num_instances, st.num_bin_entries, T, w * h,
                                    bins, bin_local=int(st.sort_path) == 2)
         names = ["preprocess", "prefix_sum", "preprocess_sort", "sort", "tile_boundary", "render"]
@@ -231,7 +235,8 @@ def main():
                        "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries), "tiles": T, "output": "rgba32f" + ("+bgra8" if args.bgra8 else ""),
                        "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}",
                        "depth_order_path": {1: "global", 2: "bin-local"}.get(int(st.sort_path), "?"),
-                       "max_bin_entries": int(st.max_bin_entries), "bins": bins, "bin_tiles": bin_edge},
+                       "max_bin_entries": int(st.max_bin_entries), "bins": bins, "bin_tiles": bin_edge,
+                       "sort_level": int(st.sort_level), "exp": "v_exp_f32" if args.hw_exp else "pipeline-defined (exact)"},
             # the K-step region is timed `batches` times (each bracketed by barrier + synchronize); value / ms_per_step
             # are the median batch, spread = (max - min) / median over the batches
             "timed": {"batches": len(batch_s), "seconds": round(float(np.sum(batch_s)), 4),
@@ -337,7 +342,34 @@ def cpu_baseline(n, w, h):
         dt = time.perf_counter() - t0
         if dt >= budget or frames >= 64:
             break
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+    # the same frame on ONE core (SURVEY 8d / BASELINE.md section 3 ask for both): one frame is the bounded sample
+    all_threads = oracle.num_threads()
+    oracle.set_num_threads(1)
+    t1 = time.perf_counter()
+    _, st1 = oracle.render_frame(verts, cov, u, want_image=True)
+    dt1 = time.perf_counter() - t1
+    oracle.set_num_threads(all_threads)
+    one_core = {"value": round(1.0 / dt1, 4), "unit": "frames/s", "cores": 1, "sample": f"1 frame in {dt1:.1f} s",
+                "ms_per_pass": [round(x, 1) for x in st1.ms]}
+    # the reference's OWN shader text compiled for the CPU (oracle/_ref; built where /root/reference is mounted and
+    # shipped as a prebuilt file): one frame of the per-frame passes, scalar GLSL invocations, OpenMP over workgroups
+    reference_text = None
+    try:
+        ref = entry.load_ref()
+        if ref.available():
+            rcov = ref.cov3d(verts)
+            tr = time.perf_counter()
+            rst = ref.stages(verts, u, cov=rcov)
+            dtr = time.perf_counter() - tr
+            reference_text = {"value": round(1.0 / dtr, 4), "unit": "frames/s", "cores": all_threads, "kind": "reference",
+                              "sample": f"1 frame in {dtr:.1f} s: src/shaders/*.comp compiled for the CPU (oracle/build_ref.py), "
+                                        "one scalar invocation per thread slot, prefix_sum.comp's ceil(log2 N)+1 passes as written, "
+                                        "std::stable_sort in place of the 8 radix passes",
+                              "max_abs_vs_port": float(np.abs(rst["image"] - ref_img).max())}
+    except Exception as e:  # baseline garnish only: never fail the bench line over it
+        reference_text = {"error": str(e)}
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": all_threads, "kind": "port", "one_core": one_core,
+            "reference_text": reference_text,
             "sample": f"{frames} frame(s) of the same workload (N={n}, {w}x{h}, D={st.num_instances}) in {dt:.1f} s wall; "
                       "oracle = CPU restatement of the reference shaders, OpenMP over Gaussians/tiles, AVX2 blend (8 pixels per step), "
                       "sliced parallel LSD sort",

@@ -75,6 +75,9 @@ typedef struct {
     uint32_t num_bin_entries; /* E1: (bin, Gaussian) candidates of the tile binning's first level */
     uint32_t max_bin_entries; /* candidates in the fullest bin */
     uint32_t sort_path;       /* depth-order path the frame took: 1 = global, 2 = bin-local (gs_set_sort_path) */
+    uint32_t bin_tiles;       /* edge of the frame's bins in tiles (4, 8, 16 or 32) */
+    uint32_t sort_level;      /* 0 / 1 / 2: in-LDS order of up to 4096 / 8192 / 16384 candidates per bin; 3: global path */
+    uint32_t pad_;
 } gs_frame_stats;
 
 /* Stage taps for parity tests (the role of Buffer::download / assertEquals,
@@ -190,6 +193,13 @@ int gs_set_sort_path(gs_renderer* r, int mode);
  *      ULP of mode 0 apart from rare alpha-threshold flips (render.comp:78), still <= 1e-4 of the reference elsewhere.
  * GS_EXP_MODE sets the initial mode for hosts that cannot call this (the viewer). */
 int gs_set_exp_mode(gs_renderer* r, int mode);
+/* Replay frames as ONE captured HIP graph each (answers VulkanContext.h:6 / Renderer.cpp:391-395, 532-717: the
+ * reference re-records its render command buffer every frame because dispatch sizes depend on D; here every grid is
+ * data-independent, so a frame's launches are captured once per configuration -- resolution, depth-order level,
+ * capacity -- and what changes per frame, the uniforms and the output pointers, is read by the kernels from a small
+ * parameter block refreshed by one copy ahead of the launch).  Per-pass spans are not recorded in this mode
+ * (ms_total still is).  Default off: it lowers the host's cost per frame, not the GPU's.  GS_GRAPH=1 sets the initial mode. */
+int gs_set_graph_mode(gs_renderer* r, int enabled);
 /* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
  * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
 int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset);

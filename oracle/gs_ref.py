@@ -102,11 +102,13 @@ def render(attr, boundaries, payload, width, height):
     return rgba
 
 
-def stages(verts, uniforms):
-    """Same dictionary as gs_oracle.stages, every stage computed by the reference's shader text."""
+def stages(verts, uniforms, cov=None):
+    """Same dictionary as gs_oracle.stages, every stage computed by the reference's shader text.
+    cov: the load-time precomp_cov3d result, when the caller times the per-frame passes only."""
     w, h = int(uniforms["width"][0]), int(uniforms["height"][0])
     tx, ty = (w + 15) // 16, (h + 15) // 16
-    cov = cov3d(verts)
+    if cov is None:
+        cov = cov3d(verts)
     attr, tiles = preprocess(verts, cov, uniforms)
     prefix = inclusive_scan(tiles)
     keys, payload = duplicate(attr, prefix, tx)

@@ -45,8 +45,8 @@ def test_committed_bench_line_has_every_contract_field():
 def test_algorithmic_bytes_model():
     m = _bench_module()
     n, v, d, e1, t, p = 1_000_000, 483_640, 4_893_565, 1_082_561, 8160, 1920 * 1080
-    assert m.bin_grid(1920, 1080) == (4, 30 * 17) and m.bin_grid(3840, 2160) == (8, 30 * 17)
-    assert m.bin_grid(256, 256) == (4, 16) and m.bin_grid(7680, 4320) == (16, 30 * 17)
+    assert m.bin_count(1920, 1080, 8) == 15 * 9 and m.bin_count(1920, 1080, 4) == 30 * 17
+    assert m.bin_count(3840, 2160, 8) == 30 * 17 and m.bin_count(256, 256, 8) == 4
     g = m.algorithmic_bytes(n, v, d, e1, t, p, 510, bin_local=False)
     b = m.algorithmic_bytes(n, v, d, e1, t, p, 510, bin_local=True)
     assert g["render"] == b["render"] == 40 * d + 16 * p

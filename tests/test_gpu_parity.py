@@ -558,3 +558,64 @@ def test_ply_larger_than_4_gib(pkg, oracle, gpu, tmp_path):
     z = scene.download_vertex_range(12345678, 1)[0]
     assert z[4] == 1.0 and z[5] == 1.0 and z[6] == 1.0 and z[7] == 0.5 and not z[:3].any()
     scene.close()
+
+
+def test_graph_replay_mode(pkg, oracle, gpu, monkeypatch):
+    """gs_set_graph_mode: a frame's launches are captured once per configuration and replayed; the uniforms and the
+    targets of each frame come from the parameter block.  A moving camera with three frames in flight, a resolution
+    change, a capacity overflow (grow + re-capture) and the fp16-SH switch must all give the oracle's frames."""
+    monkeypatch.setenv("GS_INITIAL_CAPACITY", "200000")
+    rec = pkg.synth.synth_records(20000, seed=81, kind="A")
+    verts = oracle.activate_records(rec)
+    scene = pkg.Scene.from_records(rec, device=0)
+    rend = pkg.Renderer(scene)
+    rend.set_graph_mode(True)
+    rend.set_frames_in_flight(3)
+    dev = _HipBuffers()
+    for (w, h) in [(640, 360), (800, 448)]:   # the second size overflows the 200 000-entry capacity
+        poses = [dict(position=(0.03 * k, -0.02 * k, 0.05 * k), rotation=pkg.dist.pose_quaternion(k, 1.5)) for k in range(7)]
+        targets = [dev.alloc(w * h * 16) for _ in poses]
+        for cam, ptr in zip(poses, targets):
+            rend.render(pkg.camera_uniforms(pkg.make_camera(**cam), w, h), ptr, 0)
+        rend.synchronize()
+        for cam, ptr in zip(poses, targets):
+            ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(**cam), w, h))["image"]
+            np.testing.assert_array_equal(dev.download(ptr, (h, w, 4), np.float32), ref)
+    assert rend.stats().retries >= 1
+    # stage taps and stats still work in this mode; the total span is recorded, the per-pass ones are not
+    u = pkg.camera_uniforms(pkg.make_camera(), 800, 448)
+    img, _ = rend.render_host(u)
+    ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), 800, 448))
+    compare_stages(pkg, rend, u, ref)
+    st = rend.stats()
+    assert st.ms_total > 0 and st.ms_render == 0
+    scene.quantize_sh()  # changes what preprocess reads: the captured launches must follow
+    verts16 = verts.copy()
+    verts16["sh"] = verts["sh"].astype(np.float16).astype(np.float32)
+    img16, _ = rend.render_host(u)
+    np.testing.assert_array_equal(img16.view(np.uint32), oracle.stages(verts16, oracle.camera_uniforms(oracle.default_camera(), 800, 448))["image"].view(np.uint32))
+    rend.set_graph_mode(False)
+    img2, _ = rend.render_host(u)
+    np.testing.assert_array_equal(img2, img16)
+    dev.close()
+    rend.close()
+    scene.close()
+
+
+def test_bins_are_refined_before_the_global_path(pkg, oracle, gpu, monkeypatch):
+    """Automatic mode, a cluster that puts > 16384 candidates into one 8 x 8-tile bin but fits once the bins are
+    4 x 4 tiles: the frame is re-run with the smaller bins and stays on the bin-local path (what keeps 6 M-Gaussian
+    scenes there); the lists and the pixels are the oracle's."""
+    monkeypatch.setenv("GS_SORT_PATH", "0")
+    rec = pkg.synth.synth_records(60000, seed=91, kind="A")
+    rec[:, 0] = rec[:, 0] * 0.10 + 0.3      # ~ +-58 px at 1080p, depth 4: about 2 x 2 bins of 64 px
+    rec[:, 1] = rec[:, 1] * 0.10 - 0.2
+    rec[:, 2] = -4.0 + 0.05 * rec[:, 2]
+    rec[:, 55:58] -= 1.2                     # small splats: a tile box rarely spans two 64-px bins
+    w, h = 1920, 1080
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
+    st = rend.stats()
+    assert st.retries >= 1 and st.sort_path == 2 and st.bin_tiles == 4, (st.retries, st.sort_path, st.bin_tiles, st.max_bin_entries)
+    assert st.max_bin_entries <= 16384
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
