@@ -199,6 +199,21 @@ def main():
     rend.synchronize()
     serial_fps = 100 / (time.perf_counter() - ts)
     ssum, sframes = rend.timing_totals(reset=True)
+    # diagnostic only: the default region again with the blend on the hardware's v_exp_f32 (gs_set_exp_mode(1): pixels
+    # within a few ULP of the default, see tests) -- what the opt-in mode is worth on this box
+    alt_fps = None
+    if not args.hw_exp:
+        rend.set_frames_in_flight(args.frames_in_flight)
+        rend.set_exp_mode(1)
+        for i in range(20):
+            submit(i)
+        rend.synchronize()
+        ta = time.perf_counter()
+        for i in range(args.steps):
+            submit(i)
+        rend.synchronize()
+        alt_fps = args.steps / (time.perf_counter() - ta)
+        rend.set_exp_mode(0)
     if rank == 0:
         fps = world * args.steps / elapsed
         T = ((w + 15) // 16) * ((h + 15) // 16)
@@ -249,6 +264,7 @@ def main():
                          if len(intervals) else None),
             "gpu_ms_per_frame": round(sums.ms_total / max(frames, 1), 4),
             "frames_per_s_one_in_flight": round(serial_fps, 2),  # diagnostic: one frame at a time (latency-bound)
+            "frames_per_s_hw_exp": round(alt_fps, 2) if alt_fps else None,  # diagnostic: this rank, opt-in exp mode
             "passes": per_pass,
             "passes_serial_ms": {k: round(getattr(ssum, "ms_" + k) / max(sframes, 1), 4) for k in names + ["total"]},
             "roofline": roofline(pkg, dom, n, w, h, nbytes[dom], ms[dom], serial[dom]),

@@ -607,11 +607,11 @@ def test_bins_are_refined_before_the_global_path(pkg, oracle, gpu, monkeypatch):
     4 x 4 tiles: the frame is re-run with the smaller bins and stays on the bin-local path (what keeps 6 M-Gaussian
     scenes there); the lists and the pixels are the oracle's."""
     monkeypatch.setenv("GS_SORT_PATH", "0")
-    rec = pkg.synth.synth_records(60000, seed=91, kind="A")
-    rec[:, 0] = rec[:, 0] * 0.10 + 0.3      # ~ +-58 px at 1080p, depth 4: about 2 x 2 bins of 64 px
-    rec[:, 1] = rec[:, 1] * 0.10 - 0.2
+    rec = pkg.synth.synth_records(80000, seed=91, kind="A")
+    rec[:, 0] = rec[:, 0] * 0.35 + 0.3      # a cluster ~400 px across at 1080p, depth 4: ~19 k candidates in the fullest
+    rec[:, 1] = rec[:, 1] * 0.35 - 0.2      # 128-px bin, ~9 k in the fullest 64-px one (counted with the oracle's boxes)
     rec[:, 2] = -4.0 + 0.05 * rec[:, 2]
-    rec[:, 55:58] -= 1.2                     # small splats: a tile box rarely spans two 64-px bins
+    rec[:, 55:58] -= 1.5                     # small splats: a tile box rarely spans two 64-px bins
     w, h = 1920, 1080
     scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
     st = rend.stats()

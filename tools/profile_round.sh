@@ -5,10 +5,12 @@
 # Kernel-trace/stats runs and the PMC runs are separate commands (counters never share a run with a trace domain
 # other than the kernel trace; FETCH_SIZE and WRITE_SIZE each get their own pass).
 set -u
-TAG=${1:-r01}
+exec < /dev/null
+TAG=${1:-r02}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"/{default,serial,configE,pmc,fetch,write}
+python -c "import __graft_entry__ as e; print(e.load_package().binding.library_source_hash())" > "$OUT/source_hash.txt"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline"
 PMC="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"
@@ -33,5 +35,8 @@ python bench.py --steps 200 --warmup 20 > "$OUT/bench_default.json" 2>/dev/null
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --gaussians 6000000 --width 3840 --height 2160 \
     > "$OUT/bench_configE.json" 2>/dev/null
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --gaussians 6000000 > "$OUT/bench_configC_standin.json" 2>/dev/null
+python bench.py --steps 200 --warmup 20 --no-cpu-baseline --hw-exp > "$OUT/bench_default_hwexp.json" 2>/dev/null
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --gaussians 6000000 --width 3840 --height 2160 --sh16 \
+    > "$OUT/bench_configE_sh16.json" 2>/dev/null
 ls -R "$OUT" | head -40
 tail -c 400 "$OUT/bench_default.json"

@@ -11,7 +11,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -120,21 +120,14 @@ if pmc:
                                "fetch_scale is the gfx950 correction (FETCH_SIZE reports half of a wide coalesced "
                                "streaming read: applied to k_preprocess; the blend's 16-byte gathers are left raw). "
                                "Infinity-Cache hits are counted as traffic.  valu_wave_insts = SQ_INSTS_VALU per launch.",
+                   "library_source_sha256": open(os.path.join(src, "source_hash.txt")).read().strip()
+                   if os.path.exists(os.path.join(src, "source_hash.txt")) else None,
                    "gaussians": n, "width": 1920, "height": 1080, "kernels": kernels}, f, indent=1)
     print("wrote", tag + "_pmc_hbm_traffic.json")
 
-for name in ("bench_default", "bench_configE", "bench_configC_standin"):
+for name in ("bench_default", "bench_configE", "bench_configC_standin", "bench_default_hwexp", "bench_configE_sh16"):
     b = bench_line(os.path.join(src, name + ".json"))
     if b:
-        if name == "bench_default" and pmc and "gs::k_blend" in pmc:
-            # the line was printed before this round's counter file existed: quote it against the fresh counters
-            kb = mean(fetch["gs::k_blend"]["FETCH_SIZE"]) + mean(write["gs::k_blend"]["WRITE_SIZE"])
-            insts = mean(pmc["gs::k_blend"]["SQ_INSTS_VALU"])
-            ms = b["passes"]["render"]["ms"]
-            peak = 1024 / 1.09e-9
-            b["roofline"]["traffic"] = int(kb * 1024)
-            b["roofline"]["valu"] = {"wave_insts": round(insts), "achieved_per_s": round(insts / (ms * 1e-3), 3),
-                                     "peak_per_s": round(peak, 3), "frac": round(insts / (ms * 1e-3) / peak, 4)}
         with open(os.path.join(dst, "%s_%s.json" % (tag, name)), "w") as f:
             json.dump(b, f)
             f.write("\n")
