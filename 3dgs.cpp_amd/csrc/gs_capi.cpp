@@ -614,6 +614,7 @@ struct gs_renderer {
     void init() {
         HIP_CHECK(hipSetDevice(scene->device));
         HIP_CHECK(gs::bin_prepare_device());
+        if (std::getenv("GS_DEBUG_OCCUPANCY")) gs::bin_debug_occupancy();
         for (auto& sl : slots) {
             // span timestamps only: no system-scope fence (L2 write-back) between the passes; `done` keeps the fence
             for (auto& e : sl.ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));

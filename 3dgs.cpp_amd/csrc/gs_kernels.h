@@ -114,6 +114,7 @@ struct BinLaunch {
     int grid_shift;             // 4 or 5: padded bin id = by << grid_shift | bx
 };
 uint32_t bin_level1_blocks(uint32_t n_items);
+void bin_debug_occupancy();
 hipError_t bin_prepare_device();                                    // once per device, before the first launch_bin_level2
 void launch_bin_level1_count(const BinLaunch& b, hipStream_t s);    // k_l1_hist, k_l1_scan
 // any_order: the candidates of a bin may land in any order inside each block's run (the bin-local path with bins of

@@ -17,6 +17,7 @@
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <cstdio>
 
 namespace gs {
 
@@ -1092,8 +1093,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
     __shared__ uint32_t s_seg;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const uint32_t bin = blockIdx.x;
-    if (!bin_on_screen(a.g, bin)) return;  // padding of the bin grid: no tiles
+    const uint32_t bin = ((blockIdx.x / a.g.bins_x) << a.g.grid_shift) | (blockIdx.x % a.g.bins_x);  // on-screen bins only
     BUILD_T(0);
     uint32_t c, off;
     {   // this bin's count and offset (exclusive scan over the <= 1024 bins of the padded grid)
@@ -1403,8 +1403,9 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     __shared__ uint32_t s_seg0, s_flag;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const uint32_t bin = blockIdx.x;
-    if (!bin_on_screen(a.g, bin)) return;  // padding of the bin grid: no tiles
+    // one workgroup per ON-SCREEN bin (the grid is bins_x * bins_y: with the padding of the bin grid in it, workgroups
+    // that exit at once upset the dispatcher's placement and a few CUs end up with three of the real ones)
+    const uint32_t bin = ((blockIdx.x / a.g.bins_x) << a.g.grid_shift) | (blockIdx.x % a.g.bins_x);
     BUILD_T(0);
     uint32_t c, off;
     {   // this bin's count and offset (the padded grid has <= 1024 = THREADS bins)
@@ -1768,6 +1769,22 @@ static hipError_t fast_prepare() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_fast<ROUNDS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(FastLayout<ROUNDS>::WORDS * sizeof(uint32_t)));
 }
+// debug: what the runtime says about residency of the per-bin kernels (GS_DEBUG_OCCUPANCY=1 at renderer creation)
+void bin_debug_occupancy() {
+    int n4 = -1, n8 = -1, n16 = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, reinterpret_cast<const void*>(&k_bin_fast<4>), 1024,
+                                                       FastLayout<4>::WORDS * sizeof(uint32_t));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n8, reinterpret_cast<const void*>(&k_bin_fast<8>), 1024,
+                                                       FastLayout<8>::WORDS * sizeof(uint32_t));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, reinterpret_cast<const void*>(&k_bin_fast<16>), 1024,
+                                                       FastLayout<16>::WORDS * sizeof(uint32_t));
+    hipFuncAttributes a4{}, a8{};
+    (void)hipFuncGetAttributes(&a4, reinterpret_cast<const void*>(&k_bin_fast<4>));
+    (void)hipFuncGetAttributes(&a8, reinterpret_cast<const void*>(&k_bin_fast<8>));
+    std::fprintf(stderr, "[occupancy] k_bin_fast<4>: %d blocks/CU (regs %d, static lds %zu, dyn %zu); <8>: %d (regs %d); <16>: %d\n", n4,
+                 a4.numRegs, a4.sharedSizeBytes, FastLayout<4>::WORDS * sizeof(uint32_t), n8, a8.numRegs, n16);
+}
+
 hipError_t bin_prepare_device() {  // once per device (gs_renderer::init)
     hipError_t e = build_prepare<4, 1024, true>();
     if (e == hipSuccess) e = build_prepare<16, 1024, true>();
@@ -1795,7 +1812,7 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
     a.sorted_gid = b.sorted_gid;
     a.counters = b.counters;
     a.capacity = b.capacity;
-    const uint32_t bins = 1u << (2 * b.grid_shift);
+    const uint32_t bins = b.bins_x * b.bins_y;  // on-screen bins: the kernels map the block index onto the padded grid
     const bool sort = level < 3;
     if (sort && b.bin_shift <= 3) {  // bins of 4 x 4 or 8 x 8 tiles: the all-in-LDS kernel, sized by the level
         if (level == 0) hipLaunchKernelGGL(k_bin_fast<4>, dim3(bins), dim3(1024), FastLayout<4>::WORDS * sizeof(uint32_t), s, a);

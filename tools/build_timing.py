@@ -29,3 +29,8 @@ print(f"bins {len(t)} max_bin {st.max_bin_entries} E1 {st.num_bin_entries} D {st
 for k in range(7):
     print(f"  {names[k]:16s} mean {d[:,k].mean():7.2f} us   max {d[:,k].max():7.2f}")
 print("  start spread (first to last bin start)", (t[:, 0].max() - t[:, 0].min()) / 100.0, "us")
+s0 = (t[:, 0] - t[:, 0].min()) / 100.0
+tot = (t[:, 7] - t[:, 0]) / 100.0
+print("  start offsets us: quantiles", [round(float(np.quantile(s0, q)), 1) for q in (0, .1, .25, .5, .6, .75, .9, 1)])
+late = s0 > 5
+print(f"  bins starting later than 5 us: {int(late.sum())} of {len(s0)}; mean total early {tot[~late].mean():.1f} us, late {tot[late].mean() if late.any() else 0:.1f} us")
