@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievabl
 # dense VALU load (1.09 ns per instruction and SIMD, i.e. ~1.85 GHz): a measurement, quoted beside the spec, never as it
 VALU_PEAK = 1024 * 2.4e9 / 2
 VALU_SUSTAINED = 1024 / 1.09e-9
-MIN_TIMED_SECONDS = 0.25  # a timed region shorter than this is repeated and the median batch reported
+MIN_TIMED_SECONDS = 0.5  # a timed region shorter than this is repeated and the median batch reported
 
 
 def workload_name(n, w, h, world):
