@@ -23,11 +23,12 @@ BLOB_PLANES = 59
 
 
 def library_source_hash():
-    """sha256 over the sources libgs3d_hip.so is built from: ties a committed rocprofv3 counter file to the kernels
-    it was collected on (bench.py refuses counters of other sources)."""
+    """sha256 over the KERNEL sources (and the build flags) libgs3d_hip.so is built from: ties a committed rocprofv3
+    counter file to the kernels it was collected on (bench.py refuses counters of other kernels; host-side changes do
+    not move a kernel's instruction or byte counts)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("gs_kernels.hip", "gs_kernels.h", "gs_capi.cpp", "gs_host_math.h", "Makefile"):
+    for name in ("gs_kernels.hip", "gs_kernels.h", "Makefile"):
         with open(os.path.join(_HERE, "csrc", name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()

@@ -460,11 +460,11 @@ struct FrameBuffers {
     DevBuf<gs::FrameParams> params;
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey {
-        int level = -1, hw_exp = 0;
+        int level = -1, hw_exp = 0, bin_shift = -1;
         uint32_t width = 0, height = 0, capacity = 0;
         const void *tile_order = nullptr, *ranges = nullptr, *sh16 = nullptr;
         bool operator==(const GraphKey& o) const {
-            return level == o.level && hw_exp == o.hw_exp && width == o.width && height == o.height &&
+            return level == o.level && hw_exp == o.hw_exp && bin_shift == o.bin_shift && width == o.width && height == o.height &&
                    capacity == o.capacity && tile_order == o.tile_order && ranges == o.ranges && sh16 == o.sh16;
         }
     } graph_key;
@@ -841,6 +841,7 @@ struct gs_renderer {
             HIP_CHECK(hipMemcpyAsync(fb.params.p, sl.h_params, sizeof(gs::FrameParams), hipMemcpyHostToDevice, stream));
             FrameBuffers::GraphKey key;
             key.level = lv;
+            key.bin_shift = geo.bin_shift;
             key.hw_exp = hw_exp ? 1 : 0;
             key.width = u.width;
             key.height = u.height;
