@@ -267,7 +267,7 @@ def main():
             "frames_per_s_hw_exp": round(alt_fps, 2) if alt_fps else None,  # diagnostic: this rank, opt-in exp mode
             "passes": per_pass,
             "passes_serial_ms": {k: round(getattr(ssum, "ms_" + k) / max(sframes, 1), 4) for k in names + ["total"]},
-            "roofline": roofline(pkg, dom, n, w, h, nbytes[dom], ms[dom], serial[dom]),
+            "roofline": roofline(pkg, dom, n, w, h, nbytes[dom], ms[dom], serial[dom], args.hw_exp, 1e3 * elapsed / args.steps / world),
         }
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(n, w, h)
@@ -277,7 +277,7 @@ def main():
         dist.destroy_process_group()
 
 
-def committed_counters(pkg, pass_name, n, w, h):
+def committed_counters(pkg, pass_name, n, w, h, hw_exp=False):
     """Per-launch PMC counters of the dominant kernel from the newest committed rocprofv3 counter run
     (profiles/rNN_pmc_hbm_traffic.json; FETCH_SIZE, WRITE_SIZE and the SQ counters are collected in separate passes
     by tools/profile_round.sh).  Counters cannot be collected from inside this process, so the file is only trusted
@@ -295,14 +295,15 @@ def committed_counters(pkg, pass_name, n, w, h):
             return None, f"{name} was collected on another workload"
         if prof.get("library_source_sha256") != pkg.binding.library_source_hash():
             return None, f"{name} was collected from other kernel sources than the ones this library is built from"
-        k = prof["kernels"][{"render": "k_blend", "preprocess": "k_preprocess"}[pass_name]]
+        want = {"render": "k_blend<true>" if hw_exp else "k_blend<false>", "preprocess": "k_preprocess"}[pass_name]
+        k = prof["kernels"].get(want) or prof["kernels"][want.split("<")[0]]
         return {"file": "profiles/" + name, "traffic": int((k["fetch_kb"] * k.get("fetch_scale", 1.0) + k["write_kb"]) * 1024),
                 "valu_wave_insts": int(k["valu_wave_insts"])}, None
     except (OSError, KeyError, ValueError) as e:
         return None, f"unreadable counter file: {e}"
 
 
-def roofline(pkg, pass_name, n, w, h, alg_bytes, ms_timed, ms_serial):
+def roofline(pkg, pass_name, n, w, h, alg_bytes, ms_timed, ms_serial, hw_exp=False, ms_per_frame=None):
     """Roofline of the dominant kernel.  k_blend is bound by FP32 VALU issue, not by HBM: with
     counters of this very library at hand the block is the VALU roofline (wave64 VALU instructions per launch /
     live HIP-event duration of the launch in the timed region, against 1024 SIMDs x 2.4 GHz / 2 cycles) and the HBM view
@@ -315,7 +316,7 @@ def roofline(pkg, pass_name, n, w, h, alg_bytes, ms_timed, ms_serial):
            "frac": round(gbps / HBM_PEAK_GBS, 4) if gbps else None, "algorithmic_bytes": int(alg_bytes),
            "one_in_flight": {"ms": round(ms_serial, 4), "achieved": round(gbps1, 1) if gbps1 else None,
                              "frac": round(gbps1 / HBM_PEAK_GBS, 4) if gbps1 else None}}
-    c, why = committed_counters(pkg, pass_name, n, w, h)
+    c, why = committed_counters(pkg, pass_name, n, w, h, hw_exp)
     if c is None or pass_name != "render" or not ms_timed > 0:
         return {"kernel": kernel, "bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": hbm["frac"], "traffic": c["traffic"] if c else None, "ms": round(ms_timed, 4),
@@ -331,6 +332,11 @@ def roofline(pkg, pass_name, n, w, h, alg_bytes, ms_timed, ms_serial):
                           "what": "issue rate tools/ubench/valu_rate.hip measures on this chip under dense VALU load (~1.85 GHz)"},
             "one_in_flight": {"ms": round(ms_serial, 4), "frac": round(rate1 / VALU_PEAK, 4) if rate1 else None,
                               "frac_of_sustained": round(rate1 / VALU_SUSTAINED, 4) if rate1 else None},
+            # the launches of the frames in flight overlap each other, so their spans add up to more than the wall time:
+            # one launch's instructions over the wall time of one frame (ms_per_step) is the rate the chip sustains for
+            # this kernel alongside everything else a frame needs
+            "per_frame_time": ({"ms": round(ms_per_frame, 4), "frac": round(insts / (ms_per_frame * 1e-3) / VALU_PEAK, 4)}
+                               if ms_per_frame else None),
             "hbm": hbm,
             "note": "frames overlap in the timed region (frames_in_flight), so a launch's span there includes the time it "
                     "shares the CUs with the other frames' kernels; one_in_flight is the launch with the GPU to itself"}
