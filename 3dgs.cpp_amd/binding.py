@@ -36,7 +36,7 @@ def library_source_hash():
 STAGES = dict(tiles=(0, np.uint32), depth=(1, np.float32), radius=(2, np.float32), aabb=(3, np.uint16),
               conic_opacity=(4, np.float32), uv_rg=(5, np.float32), b=(6, np.float32),
               depth_order=(7, np.uint32), sorted_tile=(11, np.uint32), sorted_gid=(12, np.uint32),
-              ranges=(13, np.uint32))
+              ranges=(13, np.uint32), lists_raw=(14, np.uint32), ranges_raw=(15, np.uint32))
 
 # every symbol include/gs3d_hip.h declares
 SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_records", "gs_scene_load_ply", "gs_scene_from_records",
@@ -286,8 +286,8 @@ class Renderer:
         st = self.stats()
         n, v, d = st.num_gaussians, st.num_visible, min(st.num_instances, st.instance_capacity)
         count = {"tiles": n, "depth": n, "radius": n, "aabb": 4 * n, "conic_opacity": 4 * n, "uv_rg": 4 * n,
-                 "b": n, "depth_order": v, "sorted_tile": d, "sorted_gid": d}.get(name)
-        if name == "ranges":
+                 "b": n, "depth_order": v, "sorted_tile": d, "sorted_gid": d, "lists_raw": d}.get(name)
+        if name in ("ranges", "ranges_raw"):
             w, h = int(uniforms["width"][0]), int(uniforms["height"][0])
             count = 2 * ((w + 15) // 16) * ((h + 15) // 16)
         out = np.zeros(max(int(count), 1), dt)

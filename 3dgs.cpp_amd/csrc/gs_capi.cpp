@@ -1420,6 +1420,8 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
                             out[pos++] = stage == GS_STAGE_SORTED_GID ? lists[i] : static_cast<uint32_t>(t);
                     return;
                 }
+            case GS_STAGE_LISTS_RAW: src = r->sorted_gid; size = d * 4; break;
+            case GS_STAGE_RANGES_RAW: src = r->last_set->ranges.p; size = r->num_tiles * 8; break;
             default: throw Error(GS_ERR_INVALID, "unknown stage");
         }
         if (bytes < size) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");

@@ -22,6 +22,9 @@
 namespace gs {
 
 #define WAVE 64
+#ifndef GS_BLEND_SALU_DIET
+#define GS_BLEND_SALU_DIET 1
+#endif
 #ifndef GS_DPP_TRANSPOSE
 #define GS_DPP_TRANSPOSE 1
 #endif
@@ -2006,7 +2009,11 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
 
             while (bm) {
                 const int k = __ffsll((unsigned long long)bm) - 1;
+#if GS_BLEND_SALU_DIET
+                asm("s_bitset0_b64 %0, %1" : "+s"(bm) : "s"(k));  // bm &= bm - 1 costs three scalar instructions
+#else
                 bm &= bm - 1;
+#endif
                 STAT_ADD(2, 1);                       // (entry, wave) pairs evaluated
                 STAT_ADD(3, __popcll(alive));         // lanes alive
                 float4 co = s_rec[w][0][k];
@@ -2040,8 +2047,15 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                         c2 = __builtin_fmaf(bp.x * alpha, T, c2);
                         T = test_T;
                     }
+#if GS_BLEND_SALU_DIET
+                    // alive &= ~mk, kept opaque: left to itself the compiler turns "did the last pixel just saturate" into
+                    // seven scalar instructions of boolean materialisation
+                    asm volatile("s_andn2_b64 %0, %0, %1" : "+s"(alive) : "s"(mk) : "scc");
+                    if (alive == 0) break;  // every pixel of the quadrant has saturated (the outer loop ends below)
+#else
                     alive &= ~mk;
                     if (alive == 0) bm = 0;
+#endif
                 }
             }
             if (alive == 0) break;

@@ -93,7 +93,9 @@ enum gs_stage {
     GS_STAGE_DEPTH_ORDER = 7,    /* uint32[V]  visible Gaussian ids, ascending (depth, id)    */
     GS_STAGE_SORTED_TILE = 11,   /* uint32[D]  == sorted key >> 32 of the reference (expanded from the ranges) */
     GS_STAGE_SORTED_GID = 12,    /* uint32[D]  == sorted payload of the reference             */
-    GS_STAGE_RANGES = 13         /* uint32[2T] == tileBoundaryBuffer                          */
+    GS_STAGE_RANGES = 13,        /* uint32[2T] == tileBoundaryBuffer                          */
+    GS_STAGE_LISTS_RAW = 14,     /* uint32[D]  the per-tile lists exactly as they lie in HBM (bin-major)            */
+    GS_STAGE_RANGES_RAW = 15     /* uint32[2T] each tile's (start, end) in GS_STAGE_LISTS_RAW; (0, 0) when empty    */
 };
 
 const char* gs_last_error(void);

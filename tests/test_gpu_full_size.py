@@ -37,6 +37,18 @@ def structural_checks(rend, u, n_tiles):
     np.testing.assert_array_equal(ranges[nz, 1] - ranges[nz, 0], counts[nz])
     np.testing.assert_array_equal(ranges[nz, 0], np.concatenate([[0], np.cumsum(counts[nz])[:-1]]))
     assert not ranges[~nz].any()
+    # the buffers as they lie in HBM (the taps above present them in tile order): the tiles' segments are disjoint,
+    # tile [0, D) exactly, and each holds that tile's list
+    raw = rend.stage("ranges_raw", u).reshape(-1, 2).astype(np.int64)
+    lists = rend.stage("lists_raw")
+    assert not raw[~nz].any()
+    np.testing.assert_array_equal(raw[nz, 1] - raw[nz, 0], counts[nz])
+    order = np.argsort(raw[nz, 0], kind="stable")
+    seg = raw[nz][order]
+    assert seg[0, 0] == 0 and seg[-1, 1] == d and (seg[1:, 0] == seg[:-1, 1]).all()
+    tiles_nz = np.nonzero(nz)[0]
+    for t in tiles_nz[:: max(1, len(tiles_nz) // 200)]:  # a sample of tiles: raw segment == presented list
+        np.testing.assert_array_equal(lists[raw[t, 0]:raw[t, 1]], sorted_gid[ranges[t, 0]:ranges[t, 1]])
     return st
 
 
