@@ -229,7 +229,9 @@ def main():
         # its duration for the roofline is the span measured inside the timed (overlapped) region
         serial = {k: getattr(ssum, "ms_" + k) / max(sframes, 1) for k in names}
         dom = max(names, key=lambda k: serial[k])
-        spread = (max(batch_s) - min(batch_s)) / elapsed if len(batch_s) > 1 else None
+        # run-to-run spread of the batches: interquartile range over the median (a single slow batch -- typically the
+        # first one, while the clocks come up -- shows in batch_ms.max, not here)
+        spread = (float(np.percentile(batch_s, 75) - np.percentile(batch_s, 25)) / elapsed) if len(batch_s) > 1 else None
         result = {
             # BASELINE.json's metric (its first clause; per-pass ms and HBM GB/s are `passes` and `roofline`); other
             # workloads (--gaussians / --width / --height) are named for what they are
@@ -253,7 +255,7 @@ def main():
                        "max_bin_entries": int(st.max_bin_entries), "bins": bins, "bin_tiles": bin_edge,
                        "sort_level": int(st.sort_level), "exp": "v_exp_f32" if args.hw_exp else "pipeline-defined (exact)"},
             # the K-step region is timed `batches` times (each bracketed by barrier + synchronize); value / ms_per_step
-            # are the median batch, spread = (max - min) / median over the batches
+            # are the median batch, spread = interquartile range / median over the batches
             "timed": {"batches": len(batch_s), "seconds": round(float(np.sum(batch_s)), 4),
                       "batch_ms": {"min": round(1e3 * min(batch_s), 4), "median": round(1e3 * elapsed, 4),
                                    "max": round(1e3 * max(batch_s), 4)},
