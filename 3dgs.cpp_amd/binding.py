@@ -23,15 +23,23 @@ BLOB_PLANES = 59
 
 
 def library_source_hash():
-    """sha256 over the KERNEL sources (and the build flags) libgs3d_hip.so is built from: ties a committed rocprofv3
-    counter file to the kernels it was collected on (bench.py refuses counters of other kernels; host-side changes do
-    not move a kernel's instruction or byte counts)."""
+    """sha256 over the KERNEL sources (comments and whitespace stripped) and the build flags libgs3d_hip.so is built from:
+    ties a committed rocprofv3 counter file to the kernels it was collected on (bench.py refuses counters of other
+    kernels; host-side or comment-only changes do not move a kernel's instruction or byte counts)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in ("gs_kernels.hip", "gs_kernels.h", "Makefile"):
-        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
-            h.update(name.encode() + b"\0" + f.read())
+        with open(os.path.join(_HERE, "csrc", name), "r") as f:
+            text = f.read()
+        if name != "Makefile":
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
+        else:
+            text = re.sub(r"#[^\n]*", " ", text)
+        h.update(name.encode() + b"\0" + " ".join(text.split()).encode())
     return h.hexdigest()
+
 
 STAGES = dict(tiles=(0, np.uint32), depth=(1, np.float32), radius=(2, np.float32), aabb=(3, np.uint16),
               conic_opacity=(4, np.float32), uv_rg=(5, np.float32), b=(6, np.float32),

@@ -43,7 +43,7 @@ struct AttrView {
 struct Counters {
     uint32_t visible;    // V
     uint32_t instances;  // D (may exceed capacity: then `overflow` is set and nothing past capacity is written)
-    uint32_t overflow;   // bit 0: a capacity (lists, candidates, chunk table) was exceeded; bit 1: a bin outgrew k_bin_sort
+    uint32_t overflow;   // bit 0: the capacity (candidates or lists) was exceeded; bit 1: a bin outgrew the in-LDS order of its level
     uint32_t bin_entries;  // E1: (bin, Gaussian) candidates of the level-1 binning
     uint32_t max_bin;    // candidates in the fullest bin
     uint32_t pad;
@@ -58,8 +58,8 @@ struct FrameParams {
     Counters* host_counters;
 };
 
-constexpr int kBinSortSmall = 4096;  // candidates per bin the 256-thread k_bin_build orders in LDS
-constexpr int kBinSortMax = 16384;   // ... and the 1024-thread one (128 KiB of (key, id))
+constexpr int kBinSortSmall = 4096;  // candidates per bin k_bin_fast orders in LDS at level 0 (x 2 per level)
+constexpr int kBinSortMax = 16384;   // ... and at level 2, the largest (128 KiB of (key, id))
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s);
 // fp32 SH block of the blob -> binary16 (round to nearest even), n x 48 values
