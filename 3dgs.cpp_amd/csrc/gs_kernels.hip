@@ -8,9 +8,10 @@
 // Reference shaders restated (paths relative to /root/reference/src/shaders):
 //   k_cov3d        precomp_cov3d.comp:25-47, common.glsl:51-75
 //   k_preprocess   preprocess.comp:34-183
-//   k_radix_*      sort/hist.comp + sort/sort.comp (result: stable ascending order)
+//   k_radix_*      sort/hist.comp + sort/sort.comp (result: stable ascending order; global depth-order path only)
 //   k_l1_*         prefix_sum.comp:32-59 + preprocess_sort.comp:31-61 (which Gaussian lands in which part of the screen)
-//   k_bin_build    the sort's result inside a bin + tile_boundary.comp:22-50 + the sorted payload
+//   k_bin_fast     the sort's result inside a bin + tile_boundary.comp:22-50 + the sorted payload (bins of <= 8 x 8 tiles)
+//   k_bin_build    the same for bins of 16 x 16 / 32 x 32 tiles and for the global path (candidates already ordered)
 //   k_blend        render.comp:30-99
 #include "gs_kernels.h"
 
