@@ -35,6 +35,15 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
                 asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
                              "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (MODE >= 9 && MODE <= 12) {
+                // 8 independent v_fma_f32 under a partial exec mask: does the hardware skip an inactive 32-lane half?
+                // 9: lanes 0-31 only; 10: lanes 32-63 only; 11: even lanes (both halves half full); 12: one lane
+                const unsigned lane = threadIdx.x & 63u;
+                const bool on = MODE == 9 ? lane < 32u : MODE == 10 ? lane >= 32u : MODE == 11 ? (lane & 1u) == 0u : lane == 0u;
+                if (on)
+                    asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                                 "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
             } else if (MODE == 4) {  // 8 v_add_f32
                 a0 += c; a1 += c; a2 += c; a3 += c; a4 += c; a5 += c; a6 += c; a7 += c;
             } else if (MODE == 5) {  // 8 v_cndmask (select on compare) + cmp
@@ -75,5 +84,9 @@ int main() {
     run<7>("asm v_fma_f32", 1, 8);
     run<8>("asm v_exp_f32", 1, 8);
     run<5>("cmp+cndmask", 1, 16);
+    run<9>("fma, lanes 0-31", 1, 8);
+    run<10>("fma, lanes 32-63", 1, 8);
+    run<11>("fma, even lanes", 1, 8);
+    run<12>("fma, one lane", 1, 8);
     return 0;
 }
