@@ -103,3 +103,40 @@ def test_equal_depth_ties_keep_index_order(pkg, oracle, ref):
         rec[:, 2] = -4.0   # same world z under the default camera -> identical depth bits in every tile
     so, sr, _ = run_case(pkg, oracle, ref, 4_000, "A", 128, 128, seed=9, mutate=ties)
     assert len(np.unique(so["attr"]["depth"][so["tiles"] > 0])) == 1
+
+
+def test_reference_text_against_the_float64_numpy_restatement(pkg, oracle, ref):
+    """The compiled reference text against tests/np_reference.py (float64, conventional math form, written from
+    SURVEY Appendix A) -- without the C oracle in between: catches a mistake in oracle/glsl_cpu/glsl_compat.hpp
+    (matrix conventions, constructors, swizzles) that the oracle might share."""
+    import np_reference as npr
+    w, h = 160, 96
+    rec = pkg.synth.synth_records(1500, seed=11, kind="A")
+    rec[:40, 2] = np.abs(rec[:40, 2])
+    rec[40:60, 0] += 9.0
+    q = np.array([0.95, 0.05, 0.2, -0.1])
+    q /= np.linalg.norm(q)
+    pos = (0.2, -0.1, 0.4)
+    verts = oracle.activate_records(rec)   # GSScene::load's host arithmetic (not shader text)
+    u = oracle.camera_uniforms(oracle.default_camera(position=pos, rotation=tuple(q)), w, h)
+    sr = ref.stages(verts, u)
+    scene = npr.activate(rec)
+    ncam = npr.camera(pos, q, 45.0, 0.1, 1000.0, w, h)
+    S = npr.cov3d(scene)
+    ref6 = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], axis=1)
+    np.testing.assert_allclose(sr["cov3d"], ref6, rtol=2e-5, atol=3e-8)
+    pre = npr.preprocess(scene, ncam)
+    attr, tiles = sr["attr"], sr["tiles"]
+    assert len(np.nonzero(tiles != pre["tiles"])[0]) <= 3   # fp32 vs fp64 threshold flips
+    both = (tiles > 0) & (pre["tiles"] > 0)
+    assert both.sum() > 800
+    np.testing.assert_allclose(attr["conic_opacity"][both, :3], pre["conic"][both], rtol=3e-4, atol=1e-6)
+    np.testing.assert_allclose(attr["uv"][both], pre["uv"][both], rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(attr["depth"][both], pre["depth"][both], rtol=1e-5)
+    np.testing.assert_allclose(attr["color_radii"][both, :3], pre["rgb"][both], rtol=1e-4, atol=2e-6)
+    assert (attr["color_radii"][both, 3] == pre["radius"][both]).mean() > 0.995
+    pre["tiles"] = tiles.astype(np.int64)
+    pre["box"] = attr["aabb"].astype(np.int64)
+    img = npr.render(pre, w, h)
+    diff = np.abs(img[..., :3] - sr["image"][..., :3])
+    assert np.quantile(diff, 0.999) < 2e-5 and diff.max() < 5e-3
