@@ -619,3 +619,25 @@ def test_bins_are_refined_before_the_global_path(pkg, oracle, gpu, monkeypatch):
     assert st.max_bin_entries <= 16384
     compare_stages(pkg, rend, u, ref)
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+
+
+def test_hardware_exp_mode_stays_within_the_north_star_bound(pkg, oracle, gpu):
+    """gs_set_exp_mode(1): the blend uses the hardware's v_exp_f32 (what a Vulkan driver emits for exp()).  Lists and
+    ranges are untouched; the image agrees with the exact mode to ULP noise except where an entry sits within rounding
+    of one of render.comp's thresholds (counted, re-traced in float64: helpers.compare_images) -- the same statement
+    the oracle satisfies against the reference's own shader text."""
+    for n, w, h, seed in [(10000, 256, 256, 0), (60000, 960, 540, 7)]:
+        rec = pkg.synth.synth_records(n, seed=seed, kind="A")
+        scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
+        np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+        rend.set_exp_mode(1)
+        img_hw, _ = rend.render_host(u)
+        compare_stages(pkg, rend, u, ref)
+        rest, flips = compare_images(img_hw, ref["image"], ref, w, label=f"hardware exp {w}x{h}")
+        assert rest <= 1e-5
+        print(f"hardware exp, {n} @ {w}x{h}: off-threshold max {rest:.3g}, flips {[(x, y, round(d, 6)) for x, y, d, _ in flips]}")
+        rend.set_exp_mode(0)
+        img_back, _ = rend.render_host(u)
+        np.testing.assert_array_equal(img_back, img)
+        rend.close()
+        scene.close()
