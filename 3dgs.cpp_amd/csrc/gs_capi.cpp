@@ -444,9 +444,9 @@ struct FrameBuffers {
     bool blend_recorded = false;
     // per-Gaussian attributes
     DevBuf<uint32_t> tiles;
-    DevBuf<float> depth, radius, bch;
+    DevBuf<float> depth;
     DevBuf<ushort4> aabb;
-    DevBuf<float4> conic_op, uv_rg;
+    DevBuf<gs::AttrRecord> rec;  // one 64-byte record per Gaussian: what the blend gathers
     // global depth order (only allocated when that path is taken)
     DevBuf<uint32_t> dkeys[2], dvals[2];
     DevBuf<uint32_t> block_hist, digit_total;
@@ -488,11 +488,8 @@ struct FrameBuffers {
         }
         tiles.alloc(n);
         depth.alloc(n);
-        radius.alloc(n);
-        bch.alloc(n);
         aabb.alloc(n);
-        conic_op.alloc(n);
-        uv_rg.alloc(n);
+        rec.alloc(n);
         l1_hist.alloc(1025 * static_cast<size_t>(gs::bin_level1_blocks(static_cast<uint32_t>(n))));  // + the row of visible counts
         bin_count.alloc(1024);
         counters.alloc(1);
@@ -748,7 +745,7 @@ struct gs_renderer {
 
         gs::SceneView sv{scene->blob, scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n)),
                           scene->sh_half ? scene->sh16.p : nullptr};
-        gs::AttrView av{fb.tiles.p, fb.depth.p, fb.radius.p, fb.aabb.p, fb.conic_op.p, fb.uv_rg.p, fb.bch.p};
+        gs::AttrView av{fb.tiles.p, fb.depth.p, fb.aabb.p, fb.rec.p};
         gs::Counters* cnt = fb.counters.p;
 
         // the first and the last kernel of the frame clear / publish the counters themselves; the blit nodes (and
@@ -1380,11 +1377,26 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
         switch (stage) {
             case GS_STAGE_TILES: src = r->last_set->tiles.p; size = n * 4; break;
             case GS_STAGE_DEPTH: src = r->last_set->depth.p; size = n * 4; break;
-            case GS_STAGE_RADIUS: src = r->last_set->radius.p; size = n * 4; break;
+            case GS_STAGE_RADIUS:
+            case GS_STAGE_CONIC_OPACITY:
+            case GS_STAGE_UV_RG:
+            case GS_STAGE_B:
+                {   // fields of the 64-byte attribute records (only the visible Gaussians' records are written: the rest
+                    // of the tap is whatever an earlier frame left, like the reference's VertexAttribute buffer)
+                    const size_t width = stage == GS_STAGE_RADIUS || stage == GS_STAGE_B ? 1 : 4;
+                    if (bytes < n * width * 4) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
+                    std::vector<gs::AttrRecord> recs(n);
+                    if (n) HIP_CHECK(hipMemcpy(recs.data(), r->last_set->rec.p, n * sizeof(gs::AttrRecord), hipMemcpyDeviceToHost));
+                    float* out = static_cast<float*>(dst);
+                    for (uint64_t i = 0; i < n; ++i) {
+                        const gs::AttrRecord& a = recs[i];
+                        if (stage == GS_STAGE_RADIUS) out[i] = a.b_depth_r.z;
+                        else if (stage == GS_STAGE_B) out[i] = a.b_depth_r.x;
+                        else std::memcpy(out + 4 * i, stage == GS_STAGE_CONIC_OPACITY ? &a.conic_op : &a.uv_rg, 16);
+                    }
+                    return;
+                }
             case GS_STAGE_AABB: src = r->last_set->aabb.p; size = n * 8; break;
-            case GS_STAGE_CONIC_OPACITY: src = r->last_set->conic_op.p; size = n * 16; break;
-            case GS_STAGE_UV_RG: src = r->last_set->uv_rg.p; size = n * 16; break;
-            case GS_STAGE_B: src = r->last_set->bch.p; size = n * 4; break;
             case GS_STAGE_DEPTH_ORDER: src = r->depth_order; size = v * 4; break;
             case GS_STAGE_SORTED_TILE:
             case GS_STAGE_SORTED_GID:
