@@ -1208,10 +1208,6 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
         if (const char* e = std::getenv("GS_GRAPH")) r->graph_mode = std::atoi(e) != 0;  // initial gs_set_graph_mode
         if (const char* e = std::getenv("GS_EXP_MODE")) r->hw_exp = std::atoi(e) != 0;  // initial gs_set_exp_mode
         if (const char* e = std::getenv("GS_BIN_SHIFT")) r->min_bin_shift = std::min(5, std::max(2, std::atoi(e)));  // default bin edge
-        // launch-shape knobs (gs_set_tuning), for hosts that cannot call it
-        if (const char* e = std::getenv("GS_TUNE_PRE_WGS")) gs::tuning().pre_wgs = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("GS_TUNE_BLEND_LDS_PAD")) gs::tuning().blend_lds_pad = std::min(48 * 1024, std::max(0, std::atoi(e)));
-        if (const char* e = std::getenv("GS_TUNE_PRIO")) gs::tuning().prio = static_cast<int>(std::strtol(e, nullptr, 16)) & 0x333;
         if (const char* e = std::getenv("GS_SORT_PATH")) {  // initial gs_set_sort_path, for hosts that cannot call it (the viewer)
             const int mode = std::atoi(e);
             if (mode < 0 || mode > 2) throw Error(GS_ERR_INVALID, "GS_SORT_PATH must be 0 (auto), 1 (global) or 2 (bin-local)");
@@ -1364,28 +1360,6 @@ int gs_set_graph_mode(gs_renderer* r, int enabled) {
         r->graph_mode = enabled != 0;
         if (!r->graph_mode)
             for (auto& fb : r->sets) fb.drop_graph();
-    });
-}
-
-int gs_set_tuning(gs_renderer* r, const char* key, int value) {
-    return guarded([&] {
-        if (!r || !key) throw Error(GS_ERR_INVALID, "null argument");
-        r->drain();
-        gs::Tuning& t = gs::tuning();
-        const std::string k(key);
-        if (k == "pre_wgs") {
-            if (value < 0) throw Error(GS_ERR_INVALID, "pre_wgs must be >= 0 (0 = one thread per Gaussian)");
-            t.pre_wgs = value;
-        } else if (k == "blend_lds_pad") {
-            if (value < 0 || value > 48 * 1024) throw Error(GS_ERR_INVALID, "blend_lds_pad must be 0..49152 bytes");
-            t.blend_lds_pad = value;
-        } else if (k == "prio") {
-            if (value < 0 || value > 0x333 || (value & 0xCCC)) throw Error(GS_ERR_INVALID, "prio is three hex digits 0..3 (k_bin_fast, level 1, preprocess)");
-            t.prio = value;
-        } else {
-            throw Error(GS_ERR_INVALID, "unknown tuning key '" + k + "' (pre_wgs, blend_lds_pad, prio)");
-        }
-        for (auto& fb : r->sets) fb.drop_graph();  // captured launches hold the old shapes
     });
 }
 

@@ -38,7 +38,7 @@ struct AttrRecord {
     float4 conic_op;   // c00 c01 c11 opacity
     float4 uv_rg;      // u v r g
     float4 b_depth_r;  // b, depth, radius, 0
-    uint4 pad_;        // never written: the stride, not the content, is what makes an entry one line
+    uint4 pad_;        // zeros (k_preprocess writes a record as one full 64-byte line); the blend never reads it
 };
 static_assert(sizeof(AttrRecord) == 64, "one line per Gaussian");
 
@@ -67,15 +67,6 @@ struct FrameParams {
     uint8_t* bgra;
     Counters* host_counters;
 };
-
-// Launch-shape knobs (gs_set_tuning; process-wide).  They change HOW the chip is shared between the frames in flight,
-// never a result: the defaults are the measured-best configuration, the rest stays reachable for experiments.
-struct Tuning {
-    int pre_wgs = 0;        // k_preprocess: 0 = one thread per Gaussian; k > 0 = k persistent 256-thread workgroups (grid stride)
-    int blend_lds_pad = 0;  // bytes of dynamic LDS added to every k_blend workgroup: caps how many share a CU (160 KiB)
-    int prio = 0;           // s_setprio level (0..3) of k_preprocess | the level-1 kernels << 4 | k_bin_fast << 8
-};
-Tuning& tuning();
 
 constexpr int kBinSortSmall = 4096;  // candidates per bin k_bin_fast orders in LDS at level 0 (x 2 per level)
 constexpr int kBinSortMax = 16384;   // ... and at level 2, the largest (128 KiB of (key, id))

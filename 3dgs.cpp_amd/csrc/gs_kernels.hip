@@ -32,15 +32,6 @@ namespace gs {
 #ifndef GS_L1_WORDLOOP
 #define GS_L1_WORDLOOP 1
 #endif
-#ifndef GS_PRE_HOIST_COV
-#define GS_PRE_HOIST_COV 0
-#endif
-#ifndef GS_AABB_ALL
-#define GS_AABB_ALL 0
-#endif
-#ifndef GS_DEPTH_ALL
-#define GS_DEPTH_ALL 0
-#endif
 #define BLOCK 256
 
 // ---------------------------------------------------------------------------------------
@@ -162,7 +153,7 @@ void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, 
 // ---------------------------------------------------------------------------------------
 // preprocess.  One thread per Gaussian; position / cov3D / opacity are SoA planes (coalesced 256 B per
 // wave and plane); the SH block is AoS (48 contiguous floats) and is read only by lanes that survive
-// every cull.
+// every cull; the 64-byte attribute records leave the wave through LDS, four lanes writing one whole line.
 // ---------------------------------------------------------------------------------------
 constexpr float SH_C0 = 0.28209479177387814f;  // common.glsl:16-33
 constexpr float SH_C1 = 0.4886025119029199f;
@@ -173,46 +164,32 @@ struct PreUniforms {
     gs_uniforms u;
     Counters* counters;      // nullable
     const FrameParams* fp;   // nullable: the uniforms live there (graph replay)
-    int prio;                // Tuning::prio & 15
 };
 
-// Tuning::prio: waves of the memory- and latency-bound passes may issue ahead of the blend's waves they share a SIMD
-// with (the blend of another frame in flight is VALU-issue-bound; these passes are a handful of instructions between
-// long waits).  The level is workgroup-uniform; s_setprio takes an immediate.
-__device__ __forceinline__ void raise_priority(int level) {
-    if (level == 1) __builtin_amdgcn_s_setprio(1);
-    else if (level == 2) __builtin_amdgcn_s_setprio(2);
-    else if (level >= 3) __builtin_amdgcn_s_setprio(3);
-}
+// Wave-private LDS of k_preprocess: the attribute records of a wave's 64 Gaussians on their way to HBM, three planes of
+// 64 float4 with a plane stride of 68 (272 dwords = 16 mod 64: the cooperative reads of 16 consecutive lanes cover all
+// 64 banks once).
+constexpr int kPrePlane = 68, kPreStage = 3 * kPrePlane;
 
-__device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uniforms& u, const AttrView& av, uint32_t i) {
+// One Gaussian per lane; `valid` = the lane has one (the last wave of the grid is ragged: every lane takes part in the
+// wave-cooperative parts).  stage: this wave's kPreStage float4 of LDS.
+__device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uniforms& u, const AttrView& av, uint32_t i,
+                                               bool valid, float4* __restrict__ stage) {
     const size_t N = sv.stride, NC = sv.n;
     const float* __restrict__ blob = sv.blob;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
 
     const int tile_w = (int)((u.width + kTile - 1) / kTile);
     const int tile_h = (int)((u.height + kTile - 1) / kTile);
 
-    const float px = blob[(P_POS + 0) * N + i];
-    const float py = blob[(P_POS + 1) * N + i];
-    const float pz = blob[(P_POS + 2) * N + i];
-#if GS_PRE_HOIST_COV
-    // the six covariance planes are requested together with the position: one memory round trip instead of two before
-    // the culls are known (a Gaussian behind the camera then costs 36 instead of 12 bytes)
-    const float* __restrict__ cv = sv.cov3d;
-    const float s0 = cv[0 * NC + i], s1 = cv[1 * NC + i], s2 = cv[2 * NC + i];
-    const float s3 = cv[3 * NC + i], s4 = cv[4 * NC + i], s5 = cv[5 * NC + i];
-    // a use ahead of the first cull: left alone, the compiler sinks the six loads below the depth test again
-    asm volatile("" ::"v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5));
-#endif
-
+    // what a visible lane carries from the culls to the stores
     uint32_t num_tiles = 0;
-#if GS_AABB_ALL
-    ushort4 box_out = make_ushort4(0, 0, 0, 0);  // culled: an empty box (the level-1 kernels read the box alone)
-#endif
-#if GS_DEPTH_ALL
-    float depth_out = 0.0f;
-#endif
-    do {
+    float px = 0, py = 0, pz = 0, depth = 0, c00 = 0, c01 = 0, c11 = 0, opacity = 0, radii = 0, uvx = 0, uvy = 0;
+    int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+    if (valid) do {
+        px = blob[(P_POS + 0) * N + i];
+        py = blob[(P_POS + 1) * N + i];
+        pz = blob[(P_POS + 2) * N + i];
         // preprocess.comp:130-135 (position.w == 1)
         float p_hom[4], p_view[3];
 #pragma unroll
@@ -263,11 +240,9 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < 3; ++r) W.c[c][r] = u.view_mat[r * 4 + c];
-#if !GS_PRE_HOIST_COV
         const float* __restrict__ cv = sv.cov3d;
         const float s0 = cv[0 * NC + i], s1 = cv[1 * NC + i], s2 = cv[2 * NC + i];
         const float s3 = cv[3 * NC + i], s4 = cv[4 * NC + i], s5 = cv[5 * NC + i];
-#endif
         M3 Sigma;
         Sigma.c[0][0] = s0;
         Sigma.c[0][1] = s1;
@@ -287,44 +262,42 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
         const float det = m00 * m11 - m10 * m01;  // :140
         if (det <= 0.0f) break;
         const float inv_det = 1.0f / det;  // inverse(mat2) :144
-        const float c00 = m11 * inv_det;
-        const float c01 = -m01 * inv_det;
-        const float c11 = m00 * inv_det;
+        c00 = m11 * inv_det;
+        c01 = -m01 * inv_det;
+        c11 = m00 * inv_det;
 
         const float mid = 0.5f * (m00 + m11);  // :148-152
         const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
         const float lambda1 = mid + sq;
         const float lambda2 = mid - sq;
         const float lambda = fmaxf(lambda1, lambda2);
-        const float radii = ceilf(3.0f * sqrtf(lambda));
+        radii = ceilf(3.0f * sqrtf(lambda));
 
-        const float uvx = ndc2pix(ndc_x, (int)u.width);  // :158
-        const float uvy = ndc2pix(ndc_y, (int)u.height);
+        uvx = ndc2pix(ndc_x, (int)u.width);  // :158
+        uvy = ndc2pix(ndc_y, (int)u.height);
 
         // :160-165 tile box
-        const int bx0 = clampi(f2i_sat((uvx - radii) / kTile), 0, tile_w);
-        const int by0 = clampi(f2i_sat((uvy - radii) / kTile), 0, tile_h);
-        const int bx1 = clampi(f2i_sat((uvx + radii + kTile - 1) / kTile), 0, tile_w);
-        const int by1 = clampi(f2i_sat((uvy + radii + kTile - 1) / kTile), 0, tile_h);
+        bx0 = clampi(f2i_sat((uvx - radii) / kTile), 0, tile_w);
+        by0 = clampi(f2i_sat((uvy - radii) / kTile), 0, tile_h);
+        bx1 = clampi(f2i_sat((uvx + radii + kTile - 1) / kTile), 0, tile_w);
+        by1 = clampi(f2i_sat((uvy + radii + kTile - 1) / kTile), 0, tile_h);
         const uint32_t nt = (uint32_t)(bx1 - bx0) * (uint32_t)(by1 - by0);
         if (nt == 0) break;
+        depth = p_view[2];
+        opacity = blob[(size_t)P_OPACITY * N + i];
+        num_tiles = nt;
+    } while (false);
+    const bool vis = num_tiles != 0;
 
-        // :73-108 compute_sh (degree 3 always; only .x clamped)
-        const float opacity = blob[(size_t)P_OPACITY * N + i];
-        float dx = px - u.camera_position[0];
-        float dy = py - u.camera_position[1];
-        float dz = pz - u.camera_position[2];
-        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float x = dx / len, y = dy / len, z = dz / len;
-        // the 48 SH floats of a Gaussian are contiguous (192 B = three 64-byte lines): only lanes that
-        // survived every cull fetch them, so SH traffic is 192 B per VISIBLE Gaussian
+    // ---- the SH block of the visible Gaussians: 48 contiguous floats each (192 B = three 64-byte lines); only lanes
+    // that survived every cull need them, so SH traffic is 192 B per VISIBLE Gaussian
+    // (A wave-cooperative fetch -- twelve lanes reading the twelve 16-byte chunks of one Gaussian, three full-line requests
+    // instead of twelve quarter-line ones, the chunks handed to their owner through LDS -- measured 5 us SLOWER: 106 VGPRs
+    // instead of 73 while chunks and coefficients are live together, four waves per SIMD instead of six.)
+    float rgb[3] = {0.0f, 0.0f, 0.0f};
+    if (vis) {
         float sh[48];
-#ifdef GS_TIMING_NO_SH  // timing experiment only (wrong colours): what the SH fetch costs
-        for (int q = 0; q < 48; ++q) sh[q] = opacity * (float)q;
-        if (false) {
-#else
-        if (sv.sh16) {
-#endif  // opt-in binary16 storage (gs_scene_quantize_sh): 96 B per visible Gaussian, widened exactly
+        if (sv.sh16) {  // opt-in binary16 storage (gs_scene_quantize_sh): 96 B per visible Gaussian, widened exactly
             const uint4* __restrict__ shv = reinterpret_cast<const uint4*>(sv.sh16) + (size_t)i * 6;
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
@@ -347,7 +320,12 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
                 sh[4 * q + 3] = t.w;
             }
         }
-        float rgb[3];
+        // :73-108 compute_sh (degree 3 always; only .x clamped)
+        float dx = px - u.camera_position[0];
+        float dy = py - u.camera_position[1];
+        float dz = pz - u.camera_position[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx / len, y = dy / len, z = dz / len;
         const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
                     C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
         const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
@@ -378,46 +356,39 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
         }
         if (rgb[0] < 0.0f) rgb[0] = 0.0f;
 
-        num_tiles = nt;
-#if GS_DEPTH_ALL
-        depth_out = p_view[2];
-#else
-        av.depth[i] = p_view[2];
-#endif
-#if GS_AABB_ALL
-        box_out = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1, (unsigned short)by1);
-#else
-        av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1,
-                                  (unsigned short)by1);
-#endif
-        // the 64-byte-strided record: three 16-byte stores to one line (writing the unused last quarter as well, to
-        // complete the line, measured no faster in the frame and 2.5 us slower here)
-        AttrRecord* rec = av.rec + i;
-#ifdef GS_TIMING_NO_STORE  // timing experiment only: what the record stores cost (one store keeps the values live)
-        if (c00 + c01 + c11 + opacity + uvx + uvy + rgb[0] + rgb[1] + rgb[2] + radii == 12345.678f) rec->conic_op = make_float4(c00, c01, c11, opacity);
-#else
-        rec->conic_op = make_float4(c00, c01, c11, opacity);
-        rec->uv_rg = make_float4(uvx, uvy, rgb[0], rgb[1]);
-        rec->b_depth_r = make_float4(rgb[2], p_view[2], radii, 0.0f);
-#endif
-    } while (false);
-    av.tiles[i] = num_tiles;  // :128 / :176
-#if GS_AABB_ALL
-    av.aabb[i] = box_out;     // every lane: full lines, and a culled Gaussian's box is empty
-#endif
-#if GS_DEPTH_ALL
-    av.depth[i] = depth_out;
-#endif
+        av.depth[i] = depth;
+        av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1, (unsigned short)by1);
+    }
+    if (valid) av.tiles[i] = num_tiles;  // :128 / :176
+
+    // ---- the 64-byte-strided record of every visible Gaussian.  Wave-cooperative: the records pass through LDS and four
+    // lanes write one record -- ONE 64-byte request per visible Gaussian (the last quarter as zeros) instead of three
+    // 16-byte ones from its own lane: k_preprocess 39 -> 37 us (without any record store it takes 30).
+    const uint64_t vm = __ballot(vis);
+    if (vis) {
+        stage[0 * kPrePlane + lane] = make_float4(c00, c01, c11, opacity);
+        stage[1 * kPrePlane + lane] = make_float4(uvx, uvy, rgb[0], rgb[1]);
+        stage[2 * kPrePlane + lane] = make_float4(rgb[2], depth, radii, 0.0f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        float4* const rec0 = reinterpret_cast<float4*>(av.rec + (i - lane));  // the wave's first record (never dereferenced past n)
+        const uint32_t c = lane & 3u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t r = (uint32_t)t * 16u + (lane >> 2);
+            if ((vm >> r) & 1ull) {  // the whole line: leaving the unused quarter out (three lanes per record) measured 2 us slower
+                const float4 val = c < 3u ? stage[c * kPrePlane + r] : make_float4(0, 0, 0, 0);
+                rec0[(size_t)r * 4 + c] = val;
+            }
+        }
+    }
 }
 
-// PERSIST: a fixed number of workgroups walk the Gaussians with a grid stride (Tuning::pre_wgs), so that with several
-// frames in flight the pass holds a bounded share of the wave slots instead of competing with another frame's blend
-// for all of them; otherwise one thread per Gaussian.
-template <bool PERSIST>
 __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms pu, AttrView av) {
+    __shared__ float4 s_stage[BLOCK / WAVE][kPreStage];
     const gs_uniforms& u = pu.fp ? pu.fp->u : pu.u;  // uniform either way: scalar loads
-    raise_priority(pu.prio);
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0 && pu.counters) {  // first kernel of the frame: the counters the later kernels accumulate into
         pu.counters->visible = 0;
         pu.counters->instances = 0;
@@ -425,17 +396,7 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         pu.counters->bin_entries = 0;
         pu.counters->max_bin = 0;
     }
-    if (PERSIST) {
-        const uint32_t step = gridDim.x * BLOCK;  // i + step < 2^32: n < 2^31 and the grid never exceeds the one-thread-per-Gaussian one
-        for (; i < sv.n; i += step) preprocess_one(sv, u, av, i);
-    } else if (i < sv.n) {
-        preprocess_one(sv, u, av, i);
-    }
-}
-
-Tuning& tuning() {
-    static Tuning t;
-    return t;
+    preprocess_one(sv, u, av, i, i < sv.n, s_stage[threadIdx.x / WAVE]);
 }
 
 void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
@@ -445,11 +406,7 @@ void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView
     pu.u = u;
     pu.counters = counters;
     pu.fp = fp;
-    pu.prio = tuning().prio & 15;
-    const uint32_t full = (sv.n + BLOCK - 1) / BLOCK;
-    const uint32_t wgs = tuning().pre_wgs > 0 ? (uint32_t)tuning().pre_wgs : 0u;
-    if (wgs != 0 && wgs < full) hipLaunchKernelGGL(k_preprocess<true>, dim3(wgs), dim3(BLOCK), 0, s, sv, pu, av);
-    else hipLaunchKernelGGL(k_preprocess<false>, dim3(full), dim3(BLOCK), 0, s, sv, pu, av);
+    hipLaunchKernelGGL(k_preprocess, dim3((sv.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, sv, pu, av);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -841,7 +798,6 @@ struct L1Args {
     Counters* counters;
     uint32_t capacity;
     uint32_t nblk;
-    int prio;                   // (Tuning::prio >> 4) & 15
 };
 
 __device__ __forceinline__ bool bin_on_screen(const BinGrid& g, uint32_t bin) {
@@ -855,13 +811,8 @@ __device__ __forceinline__ uint32_t l1_item(const L1Args& a, uint32_t p, uint32_
     box_out = 0;
     if (p < n) {
         gid = a.order ? a.order[p] : p;
-#if GS_AABB_ALL
-        const ushort4 box = a.aabb[gid];  // one round trip: a culled Gaussian's box is (0, 0, 0, 0)
-        if (box.z > box.x && box.w > box.y) {
-#else
         if (a.tiles[gid] != 0) {
             const ushort4 box = a.aabb[gid];
-#endif
             const uint32_t x0 = box.x >> a.g.bin_shift, y0 = box.y >> a.g.bin_shift;
             const uint32_t x1 = ((box.z - 1u) >> a.g.bin_shift) + 1u, y1 = ((box.w - 1u) >> a.g.bin_shift) + 1u;
             box_out = x0 | (y0 << 8) | (x1 << 16) | (y1 << 24);
@@ -896,7 +847,6 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
     __shared__ uint32_t s_hist[NB];
     __shared__ uint32_t s_vis;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    raise_priority(a.prio);
     for (int b = tid; b < NB; b += BLOCK) s_hist[b] = 0;
     if (tid == 0) s_vis = 0;
     __syncthreads();
@@ -937,7 +887,6 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
 __global__ __launch_bounds__(BLOCK) void k_l1_scan(L1Args a) {
     __shared__ uint32_t scratch[8];
     const uint32_t bin = blockIdx.x;
-    raise_priority(a.prio);
     const uint32_t nb = 1u << (2 * a.g.grid_shift);
     if (bin == nb) {  // the row of per-block visible counts (bin-local path): V
         if (a.order) return;
@@ -982,7 +931,6 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
     __shared__ uint32_t s_ids[kL1Chunks][WAVE];
     __shared__ uint32_t scratch[8];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    raise_priority(a.prio);
     {   // bin offsets = exclusive scan of the bin totals (<= 1024 values: every block redoes it, no extra launch)
         uint32_t c[NB / BLOCK], sum = 0;
 #pragma unroll
@@ -1080,7 +1028,6 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     __shared__ uint32_t s_cur[NB];  // next free slot of this block's run in each bin's list
     __shared__ uint32_t scratch[8];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    raise_priority(a.prio);
     {   // bin offsets = exclusive scan of the bin totals (<= 1024 values: every block redoes it, no extra launch)
         uint32_t c[NB / BLOCK], sum = 0;
 #pragma unroll
@@ -1139,7 +1086,6 @@ struct BuildArgs {
     uint32_t* sorted_gid;  // [capacity]
     Counters* counters;
     uint32_t capacity;
-    int prio;              // (Tuning::prio >> 8) & 15
 };
 
 // candidate's tile box clipped to the bin, in bin-local tile coordinates (upper bounds exclusive), packed like l1_item's
@@ -1501,7 +1447,6 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     __shared__ uint32_t s_seg0, s_flag;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    raise_priority(a.prio);
     // one workgroup per ON-SCREEN bin (the grid is bins_x * bins_y: with the padding of the bin grid in it, workgroups
     // that exit at once upset the dispatcher's placement and a few CUs end up with three of the real ones)
     const uint32_t bin = ((blockIdx.x / a.g.bins_x) << a.g.grid_shift) | (blockIdx.x % a.g.bins_x);
@@ -1832,7 +1777,6 @@ static L1Args l1_args(const BinLaunch& b) {
     a.counters = b.counters;
     a.capacity = b.capacity;
     a.nblk = bin_level1_blocks(b.n_bound);
-    a.prio = (tuning().prio >> 4) & 15;
     return a;
 }
 
@@ -1912,7 +1856,6 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
     a.sorted_gid = b.sorted_gid;
     a.counters = b.counters;
     a.capacity = b.capacity;
-    a.prio = (tuning().prio >> 8) & 15;
     const uint32_t bins = b.bins_x * b.bins_y;  // on-screen bins: the kernels map the block index onto the padded grid
     const bool sort = level < 3;
     if (sort && b.bin_shift <= 3) {  // bins of 4 x 4 or 8 x 8 tiles: the all-in-LDS kernel, sized by the level
@@ -2178,14 +2121,12 @@ void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint
                   Counters* host_counters, bool hw_exp, const FrameParams* fp, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
-    // Tuning::blend_lds_pad: LDS the kernel never touches, only there to cap how many of its workgroups share a CU
-    const size_t pad = (size_t)std::min(48 * 1024, std::max(0, tuning().blend_lds_pad));
     if (hw_exp)
-        hipLaunchKernelGGL(k_blend<true>, dim3(tx * ty), dim3(BLOCK), pad, s, reinterpret_cast<const uint2*>(ranges),
+        hipLaunchKernelGGL(k_blend<true>, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                            sorted_gid, tile_order, av.rec, width, height, tx,
                            reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp);
     else
-        hipLaunchKernelGGL(k_blend<false>, dim3(tx * ty), dim3(BLOCK), pad, s, reinterpret_cast<const uint2*>(ranges),
+        hipLaunchKernelGGL(k_blend<false>, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                            sorted_gid, tile_order, av.rec, width, height, tx,
                            reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp);
 }

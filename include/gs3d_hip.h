@@ -202,16 +202,6 @@ int gs_set_exp_mode(gs_renderer* r, int mode);
  * parameter block refreshed by one copy ahead of the launch).  Per-pass spans are not recorded in this mode
  * (ms_total still is).  Default off: it lowers the host's cost per frame, not the GPU's.  GS_GRAPH=1 sets the initial mode. */
 int gs_set_graph_mode(gs_renderer* r, int enabled);
-/* Launch-shape knobs: how the passes of the frames in flight share the chip.  They never change a result (the same
- * arithmetic on the same data in every setting) and have no reference counterpart; PROCESS-WIDE, applied to frames
- * enqueued after the call (the renderer is synchronized first).  Keys:
- *   "pre_wgs"        0 = preprocess runs one thread per Gaussian; k > 0 = k persistent 256-thread workgroups walk the
- *                    Gaussians with a grid stride, i.e. the pass holds a bounded share of the wave slots;
- *   "blend_lds_pad"  bytes (0..49152) of unused LDS added to every blend workgroup: caps how many share a CU;
- *   "prio"           three hex digits 0..3: s_setprio level of k_bin_fast, of the level-1 kernels, of preprocess
- *                    (0x000 = everything at the blend's priority).
- * GS_TUNE_PRE_WGS / GS_TUNE_BLEND_LDS_PAD / GS_TUNE_PRIO (hex) set them at renderer creation. */
-int gs_set_tuning(gs_renderer* r, const char* key, int value);
 /* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
  * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
 int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset);

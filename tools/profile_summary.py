@@ -39,7 +39,10 @@ def kernel_stats(sub, out_name, header):
     b = bench_line(os.path.join(src, sub, "bench.json"))
     with open(os.path.join(dst, out_name), "w") as f:
         f.write("# " + header + "\n")
-        if b:
+        if b and b.get("driver"):  # tools/profile_lite.sh: the profiled process is tools/tune_sweep.py
+            f.write("# %s under the profiler: %s frames/s, %d frame(s) in flight; HIP-event spans (us) %s\n"
+                    % (b["driver"], b["value"], b["frames_in_flight"], json.dumps(b["spans_us"])))
+        elif b:
             f.write("# bench line under the profiler: value=%s frames/s ms_per_step=%s; k_blend HIP-event span in the "
                     "timed region %.4f ms (one frame at a time: %.4f ms)\n"
                     % (b["value"], b["ms_per_step"], b["passes"]["render"]["ms"], b["passes_serial_ms"]["render"]))
@@ -67,13 +70,26 @@ def mean(v):
 
 
 os.makedirs(dst, exist_ok=True)
-kernel_stats("default", tag + "_kernel_stats_default.txt",
-             "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
-             "   (MI355X, config B, 3 frames in flight = the default bench command; durations include contention from the"
-             " other frames in flight; the 100 one-in-flight diagnostic launches are pooled in)")
-kernel_stats("serial", tag + "_kernel_stats_serial.txt",
-             "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
-             " --frames-in-flight 1   (MI355X, config B, one frame at a time: clean per-kernel durations)")
+lite = (bench_line(os.path.join(src, "serial", "bench.json")) or {}).get("driver") is not None
+if lite:
+    CMD = "python tools/tune_sweep.py --no-prime --batches 1 --frames 300"
+    PMC_CMD = "python tools/tune_sweep.py --no-prime --batches 1 --fif 1 --frames 3 --warm 1"
+    kernel_stats("default", tag + "_kernel_stats_default.txt",
+                 "rocprofv3 --kernel-trace --stats --output-format csv -- " + CMD + " --fif 3   (MI355X, config B, 3 frames in "
+                 "flight like the default bench command -- the same C-ABI calls as bench.py's timed region, no torch; durations "
+                 "include contention from the other frames in flight)")
+    kernel_stats("serial", tag + "_kernel_stats_serial.txt",
+                 "rocprofv3 --kernel-trace --stats --output-format csv -- " + CMD + " --fif 1   (MI355X, config B, one frame at a "
+                 "time: clean per-kernel durations)")
+else:
+    PMC_CMD = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1"
+    kernel_stats("default", tag + "_kernel_stats_default.txt",
+                 "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+                 "   (MI355X, config B, 3 frames in flight = the default bench command; durations include contention from the"
+                 " other frames in flight; the 100 one-in-flight diagnostic launches are pooled in)")
+    kernel_stats("serial", tag + "_kernel_stats_serial.txt",
+                 "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+                 " --frames-in-flight 1   (MI355X, config B, one frame at a time: clean per-kernel durations)")
 kernel_stats("configE", tag + "_kernel_stats_configE_serial.txt",
              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline"
              " --frames-in-flight 1 --gaussians 6000000 --width 3840 --height 2160   (MI355X, config E, one frame at a time)")
@@ -81,8 +97,7 @@ kernel_stats("configE", tag + "_kernel_stats_configE_serial.txt",
 pmc, fetch, write = counters("pmc"), counters("fetch"), counters("write")
 if pmc:
     with open(os.path.join(dst, tag + "_pmc_counters.txt"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "
-                "--frames-in-flight 1  (MI355X, config B); three separate runs:\n"
+        f.write("# rocprofv3 --kernel-trace --pmc <counters> -- " + PMC_CMD + "  (MI355X, config B); three separate runs:\n"
                 "#   SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU "
                 "SQ_WAIT_ANY | FETCH_SIZE | WRITE_SIZE\n"
                 "# means per dispatch.  FETCH_SIZE / WRITE_SIZE in KB.  SQ_*_CYCLES are quad-cycles; SQ_BUSY_CYCLES is summed "
@@ -115,7 +130,7 @@ if pmc:
         kernels["k_preprocess"]["algorithmic_bytes"] = n * 40 + v * 248
     with open(os.path.join(dst, tag + "_pmc_hbm_traffic.json"), "w") as f:
         json.dump({"_comment": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate runs) "
-                               "-- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 on MI355X, "
+                               "-- " + PMC_CMD + " on MI355X, "
                                "config B.  KB per launch (mean over the launches of the run), raw counter values; "
                                "fetch_scale is the gfx950 correction (FETCH_SIZE reports half of a wide coalesced "
                                "streaming read: applied to k_preprocess; the blend's 16-byte gathers are left raw). "
