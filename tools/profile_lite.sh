@@ -21,5 +21,5 @@ timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OU
 timeout 60 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- $D --fif 1 --frames 3 --warm 1 > /dev/null 2>&1
 rm -f "$OUT"/*/*_kernel_trace.csv
 cd "$R"
-timeout 60 python tools/tune_sweep.py --fif 1,3 --json-out "$OUT/bench_default.json" | tail -3
+timeout 60 python tools/tune_sweep.py --fif 1,3 --json-out "$OUT/sweep_default.json" | tail -3
 ls -R "$OUT" | head -30

@@ -66,7 +66,14 @@ def counters(sub):
 
 
 def mean(v):
-    return sum(v) / len(v) if v else float("nan")
+    """Per-dispatch figure of a kernel: the MEDIAN over its dispatches.  (A renderer's first frame runs at the smallest
+    sort level, overflows it and is re-run: that frame's blend walks near-empty lists, and in a short counter run it
+    would pull a mean down by a fifth.)"""
+    if not v:
+        return float("nan")
+    w = sorted(v)
+    m = len(w) // 2
+    return w[m] if len(w) % 2 else 0.5 * (w[m - 1] + w[m])
 
 
 os.makedirs(dst, exist_ok=True)
@@ -100,7 +107,7 @@ if pmc:
         f.write("# rocprofv3 --kernel-trace --pmc <counters> -- " + PMC_CMD + "  (MI355X, config B); three separate runs:\n"
                 "#   SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU "
                 "SQ_WAIT_ANY | FETCH_SIZE | WRITE_SIZE\n"
-                "# means per dispatch.  FETCH_SIZE / WRITE_SIZE in KB.  SQ_*_CYCLES are quad-cycles; SQ_BUSY_CYCLES is summed "
+                "# medians over the dispatches of the run.  FETCH_SIZE / WRITE_SIZE in KB.  SQ_*_CYCLES are quad-cycles; SQ_BUSY_CYCLES is summed "
                 "over 32 shader engines.\n")
         f.write("%-30s %10s %10s %10s %12s %12s %10s %10s\n"
                 % ("kernel", "VALU_inst", "SALU_inst", "LDS_inst", "WAVE_CYCLES", "BUSY_CYCLES", "FETCH_KB", "WRITE_KB"))
@@ -113,7 +120,7 @@ if pmc:
                        mean(write[k]["WRITE_SIZE"])))
     print("wrote", tag + "_pmc_counters.txt")
 
-    b = bench_line(os.path.join(src, "bench_default.json"))
+    b = bench_line(os.path.join(src, "bench_default.json")) or bench_line(os.path.join(src, "sweep_default.json"))
     cfg = b["config"] if b else {}
     n, v, d = cfg.get("gaussians", 0), cfg.get("visible", 0), cfg.get("instances", 0)
     kernels = {}
@@ -131,7 +138,7 @@ if pmc:
     with open(os.path.join(dst, tag + "_pmc_hbm_traffic.json"), "w") as f:
         json.dump({"_comment": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate runs) "
                                "-- " + PMC_CMD + " on MI355X, "
-                               "config B.  KB per launch (mean over the launches of the run), raw counter values; "
+                               "config B.  KB per launch (median over the launches of the run), raw counter values; "
                                "fetch_scale is the gfx950 correction (FETCH_SIZE reports half of a wide coalesced "
                                "streaming read: applied to k_preprocess; the blend's 16-byte gathers are left raw). "
                                "Infinity-Cache hits are counted as traffic.  valu_wave_insts = SQ_INSTS_VALU per launch.",
