@@ -15,7 +15,7 @@ def _bench_module():
 
 
 def test_committed_bench_line_has_every_contract_field():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02b_bench_default.json")) as f:
         b = json.load(f)
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         base = json.load(f)
