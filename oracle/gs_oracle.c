@@ -2,8 +2,9 @@
  * gs_oracle.c -- CPU restatement of the shg8/3DGS.cpp splat pipeline.
  *
  * TEST INFRASTRUCTURE ONLY (parity oracle + bench.py cpu_baseline).  See
- * gs_oracle.h for the contract.  PARITY UNPINNED BY THE REFERENCE (it has no
- * golden vectors and cannot be built here); pinned by tests/test_oracle_*.py.
+ * gs_oracle.h for the contract.  PARITY PINNED TO THE REFERENCE'S OWN SHADER TEXT compiled for the CPU
+ * (oracle/build_ref.py -> oracle/_ref; tests/test_oracle_vs_ref.py): the reference ships no golden vectors and cannot
+ * be built here as a Vulkan program.
  *
  * Third-party arithmetic restated here because the dependency is not vendored
  * in /root/reference: glm 1.0.0 (CMakeLists.txt:31-35): mat4_cast, translate,
@@ -638,9 +639,20 @@ void gso_tile_boundary(const uint64_t* keys, uint64_t d, uint32_t* boundaries, u
     }
 }
 
-/* render.comp:30-99 */
+/* render.comp:30-99.
+ * GLSL lets a compiler contract a multiply and a dependent add into one FMA (no `precise` in the shader).  The
+ * pipeline's definition makes three such contractions (marked below; the HIP kernel makes the same ones), which is
+ * what gso_render evaluates.  gso_set_contraction(0) switches gso_render to the UNCONTRACTED reading -- one rounding
+ * per operation exactly as the text is written -- which is what the reference's shader text compiled for the CPU
+ * (oracle/_ref, -ffp-contract=off) evaluates: with it, oracle and reference text differ in exp() alone, for any scene.
+ * The two readings agree to ULP noise unless `power` is a difference of much larger terms (thin, long splats far from
+ * their centre), where one rounding more or less moves alpha by ~2^-24 x |terms| (tests/test_oracle_vs_ref.py). */
+static int g_contract = 1;
+void gso_set_contraction(int on) { g_contract = on != 0; }
+
 void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const uint32_t* payload,
                 uint32_t width, uint32_t height, float* rgba) {
+    const int contract = g_contract;
     const uint32_t tiles_width = (width + 16 - 1) / 16;
     const uint32_t tiles_height = (height + 16 - 1) / 16;
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
@@ -661,8 +673,13 @@ void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const u
                         const float* co = a->conic_opacity;
                         /* :66  -0.5*(co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy with the two
                          * multiply-adds GLSL allows a compiler to contract written as FMAs */
-                        float s = fmaf(co[2] * dy, dy, co[0] * dx * dx);
-                        float power = fmaf(-(co[1] * dx), dy, -0.5f * s);
+                        float power;
+                        if (contract) {
+                            float s = fmaf(co[2] * dy, dy, co[0] * dx * dx);
+                            power = fmaf(-(co[1] * dx), dy, -0.5f * s);
+                        } else { /* as written, left to right (built with -ffp-contract=off) */
+                            power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        }
                         /* :68.  A NaN power (non-finite conic or centre) also skips: GLSL leaves
                          * the comparison and the following exp(NaN) undefined; the pipeline
                          * defines "no contribution". */
@@ -671,9 +688,15 @@ void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const u
                         if (alpha < 1.0f / 255.0f) continue;
                         float test_T = T * (1 - alpha);
                         if (test_T < 0.0001f) break; /* :82-85 */
-                        c0 = fmaf(a->color_radii[0] * alpha, T, c0); /* :87, contracted */
-                        c1 = fmaf(a->color_radii[1] * alpha, T, c1);
-                        c2 = fmaf(a->color_radii[2] * alpha, T, c2);
+                        if (contract) {
+                            c0 = fmaf(a->color_radii[0] * alpha, T, c0); /* :87, contracted */
+                            c1 = fmaf(a->color_radii[1] * alpha, T, c1);
+                            c2 = fmaf(a->color_radii[2] * alpha, T, c2);
+                        } else { /* c += color * alpha * T */
+                            c0 = c0 + a->color_radii[0] * alpha * T;
+                            c1 = c1 + a->color_radii[1] * alpha * T;
+                            c2 = c2 + a->color_radii[2] * alpha * T;
+                        }
                         T = test_T;
                     }
                     float* o = rgba + ((uint64_t)py * width + px) * 4;

@@ -138,6 +138,12 @@ def render(attr, boundaries, payload, width, height, simd=False):
     return rgba
 
 
+def set_contraction(on):
+    """render(): True (default) = the pipeline's three FMA contractions; False = render.comp:66,87 uncontracted, as the
+    reference's shader text compiled for the CPU evaluates them (gso_set_contraction)."""
+    lib().gso_set_contraction(C.c_int(int(bool(on))))
+
+
 def set_simd_blend(on):
     """render_frame uses the AVX2 blend (CPU baseline timing only; the parity checks use the scalar one)."""
     lib().gso_set_simd_blend(C.c_int(int(on)))
