@@ -56,6 +56,13 @@ ULP_NOISE = 1e-5        # measured 3e-7 .. 2e-6; anything above this must be an 
 ALPHA_REL = 4e-6        # |alpha * 255 - 1| below this: alpha is within a few ULP of exp()/power of the cut
 T_REL = 2e-4            # |T' / 1e-4 - 1|: T is a product of up to thousands of factors, each a few ULP apart
 POWER_REL = 4e-6        # |power| relative to its terms
+# Contraction sensitivity.  `power` is a sum of three products; when they cancel (a splat seen far from its centre along its
+# long axis) one rounding more or less -- a contracted multiply-add, which GLSL permits and the pipeline makes, against the
+# uncontracted evaluation of the reference text compiled for the CPU -- moves `power` by ~2^-24 x |terms|, alpha by alpha x
+# that, and the pixel by T x alpha x that x |rgb|, thresholds or not.  classify_pixel() therefore (a) widens the distances
+# to the alpha and T cuts by CANCEL_SLACK x that much, and (b) sums the first-order bound of the pixel's movement over the
+# pixel's list ("cancel"): a pixel within CANCEL_SLACK x the bound is explained without any flip.
+CANCEL_SLACK = 4.0
 
 
 def classify_pixel(attr, boundaries, payload, width, px, py):
@@ -70,19 +77,26 @@ def classify_pixel(attr, boundaries, payload, width, px, py):
     power = -0.5 * (t1 + t2) - t3
     mag = 0.5 * (np.abs(t1) + np.abs(t2)) + np.abs(t3) + 1e-300
     alpha = np.minimum(0.99, co[:, 3] * np.exp(np.minimum(power, 0.0)))
-    near = dict(alpha=np.inf, power=np.inf, T=np.inf)
+    near = dict(alpha=np.inf, power=np.inf, T=np.inf, cancel=0.0)
+    rgb = np.abs(a["color_radii"][:, :3].astype(np.float64)).max(axis=1)
     T = 1.0
+    t_err = 0.0  # relative uncertainty of the running transmittance from the cancellation in the entries so far
     for k in range(len(ids)):
         near["power"] = min(near["power"], abs(power[k]) / mag[k] if mag[k] > 1e-30 else np.inf)
         if power[k] > 0:
             continue
-        near["alpha"] = min(near["alpha"], abs(alpha[k] * 255.0 - 1.0))
+        d_power = CANCEL_SLACK * 2.0 ** -24 * mag[k]  # how far one rounding of the largest term can move `power`
+        # distances to the cuts, less what the cancellation alone can move alpha / T by (relative): 0 = may flip
+        near["alpha"] = min(near["alpha"], max(0.0, abs(alpha[k] * 255.0 - 1.0) - d_power))
         if alpha[k] < 1.0 / 255.0:
             continue
         test_T = T * (1.0 - alpha[k])
-        near["T"] = min(near["T"], abs(test_T / 1e-4 - 1.0))
+        t_err += d_power * alpha[k] / max(1.0 - alpha[k], 1e-2)
+        near["T"] = min(near["T"], max(0.0, abs(test_T / 1e-4 - 1.0) - t_err))
         if test_T < 1e-4:
             break
+        # this entry's contribution and everything behind it move by at most T x alpha x d_power x max(1, |rgb|)
+        near["cancel"] += T * alpha[k] * 2.0 ** -24 * mag[k] * max(1.0, rgb[k])
         T = test_T
     return near
 
@@ -96,9 +110,12 @@ def compare_images(img, ref_img, ref, width, label=""):
     flips = []
     for py, px in zip(ys.tolist(), xs.tolist()):
         near = classify_pixel(ref["attr"], ref["boundaries"], ref["sorted_payload"], width, px, py)
-        explained = near["alpha"] < ALPHA_REL or near["T"] < T_REL or near["power"] < POWER_REL
-        flips.append((px, py, float(d[py, px]), near))
-        assert explained, f"{label} pixel ({px},{py}) differs by {d[py, px]:.3g} with no entry near a threshold: {near}"
+        flipped = near["alpha"] < ALPHA_REL or near["T"] < T_REL or near["power"] < POWER_REL
+        cancelled = d[py, px] <= CANCEL_SLACK * near["cancel"]   # contraction sensitivity of a cancelling `power`, no flip
+        assert flipped or cancelled, (f"{label} pixel ({px},{py}) differs by {d[py, px]:.3g} with no entry near a threshold "
+                                      f"and a cancellation bound of {near['cancel']:.3g}: {near}")
+        if flipped and not cancelled:
+            flips.append((px, py, float(d[py, px]), near))
     assert len(flips) <= max(3, 1e-5 * d.size), f"{label}: {len(flips)} threshold-flip pixels"
     assert d.max() <= 2.0 / 255.0 * max(1.0, float(np.abs(ref_img[..., :3]).max()))
     rest = d.copy()
