@@ -83,3 +83,17 @@ def test_roofline_block_without_counters_is_the_hbm_view(pkg):
     assert r["bound"] == "hbm" and r["traffic"] is None and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["achieved"] - 228_920_200 / 1e9 / 0.25e-3) < 1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
     assert r["one_in_flight"]["ms"] == 0.21
+
+
+def test_committed_counters_belong_to_the_library_as_built(pkg):
+    """The newest committed counter run must have been collected from the kernel sources this library is built from
+    (bench.py refuses anything else and falls back to the HBM view): a kernel edited after the last profile shows here,
+    on the CPU, before the driver's bench line would."""
+    m = _bench_module()
+    c, why = m.committed_counters(pkg, "render", 1_000_000, 1920, 1080)
+    assert c is not None, why
+    assert c["valu_wave_insts"] > 1e8 and c["traffic"] > 5e7 and c["file"].startswith("profiles/r")
+    r = m.roofline(pkg, "render", 1_000_000, 1920, 1080, 228_920_200, 0.30, 0.19, ms_per_frame=0.245)
+    assert r["bound"] == "valu" and r["peak"] == 1228.8 and r["counters"] == c["file"]
+    assert abs(r["one_in_flight"]["frac"] - c["valu_wave_insts"] / 0.19e-3 / m.VALU_PEAK) < 1e-3
+    assert abs(r["per_frame_time"]["frac"] - c["valu_wave_insts"] / 0.245e-3 / m.VALU_PEAK) < 1e-3
