@@ -52,7 +52,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_scene_num_vertices", "gs_scene_quantize_sh", "gs_scene_sh_bits", "gs_scene_download_vertex_range",
            "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
-           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_get_timing_totals",
+           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_set_blend_contraction", "gs_get_timing_totals",
            "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_renderer_stream",
            "gs_dist_unique_id", "gs_dist_create", "gs_dist_rank", "gs_dist_world", "gs_dist_pose_count",
            "gs_dist_broadcast_scene", "gs_dist_destroy"]
@@ -258,8 +258,17 @@ class Renderer:
         _check(lib().gs_set_frames_in_flight(self._h, C.c_int(int(frames))))
 
     def set_exp_mode(self, mode):
-        """0 pipeline-defined exp (exact), 1 hardware v_exp_f32 (gs_set_exp_mode)."""
+        """2 (default) libm's expf restated in binary64, 0 pipeline-defined polynomial, 1 hardware v_exp_f32 (gs_set_exp_mode)."""
         _check(lib().gs_set_exp_mode(self._h, C.c_int(int(mode))))
+
+    def set_blend_contraction(self, enabled):
+        """False (default): render.comp:66,87 as written; True: the three FMA contractions GLSL permits (gs_set_blend_contraction)."""
+        _check(lib().gs_set_blend_contraction(self._h, C.c_int(int(bool(enabled)))))
+
+    def set_fast_blend(self, fast):
+        """True: both opt-in relaxations (polynomial exp, contractions); False: the default, bit-identical to the reference text."""
+        self.set_exp_mode(0 if fast else 2)
+        self.set_blend_contraction(bool(fast))
 
     def set_graph_mode(self, enabled):
         """Replay frames as captured HIP graphs (gs_set_graph_mode)."""

@@ -460,11 +460,11 @@ struct FrameBuffers {
     DevBuf<gs::FrameParams> params;
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey {
-        int level = -1, hw_exp = 0, bin_shift = -1;
+        int level = -1, hw_exp = 0, contract = 1, bin_shift = -1;
         uint32_t width = 0, height = 0, capacity = 0;
         const void *tile_order = nullptr, *ranges = nullptr, *sh16 = nullptr;
         bool operator==(const GraphKey& o) const {
-            return level == o.level && hw_exp == o.hw_exp && bin_shift == o.bin_shift && width == o.width && height == o.height &&
+            return level == o.level && hw_exp == o.hw_exp && contract == o.contract && bin_shift == o.bin_shift && width == o.width && height == o.height &&
                    capacity == o.capacity && tile_order == o.tile_order && ranges == o.ranges && sh16 == o.sh16;
         }
     } graph_key;
@@ -574,7 +574,8 @@ struct gs_renderer {
     static uint32_t level_limit(int lv) { return static_cast<uint32_t>(gs::kBinSortSmall) << lv; }
     int frame_level() const { return sort_mode == 1 ? kGlobalLevel : level; }
     bool graph_mode = false;     // replay each frame as one captured HIP graph (gs_set_graph_mode)
-    bool hw_exp = false;         // blend with the hardware's v_exp_f32 instead of the pipeline-defined exp (gs_set_exp_mode)
+    int exp_mode = 2;            // the blend's exp(): 2 libm's expf restated in binary64 (default), 0 pipeline polynomial, 1 hardware v_exp_f32 (gs_set_exp_mode)
+    bool contract = false;       // the three FMA contractions GLSL permits in render.comp:66,87 (gs_set_blend_contraction); default: as written
     int min_bin_shift = 3;       // GS_BIN_SHIFT: log2 of the default bin edge in tiles (8 x 8 tiles)
     bool refined = false;        // bins of half that edge: taken when a bin outgrows the largest in-LDS order
     bool have_frame = false;
@@ -827,7 +828,7 @@ struct gs_renderer {
                 HIP_CHECK(hipStreamWaitEvent(bstream, fb.prep_done, 0));
             }
             gs::launch_blend(fb.ranges.p, fb.sorted.p, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
-                             fused_counters ? sl.h_counters : nullptr, hw_exp, fp, bstream);
+                             fused_counters ? sl.h_counters : nullptr, exp_mode, contract, fp, bstream);
         };
         depth_order = bin_local ? nullptr : fb.dvals[1].p;
         sorted_gid = fb.sorted.p;
@@ -839,7 +840,8 @@ struct gs_renderer {
             FrameBuffers::GraphKey key;
             key.level = lv;
             key.bin_shift = geo.bin_shift;
-            key.hw_exp = hw_exp ? 1 : 0;
+            key.hw_exp = exp_mode;
+            key.contract = contract ? 1 : 0;
             key.width = u.width;
             key.height = u.height;
             key.capacity = capacity;
@@ -1206,7 +1208,8 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
         r->scene = scene;
         r->init();
         if (const char* e = std::getenv("GS_GRAPH")) r->graph_mode = std::atoi(e) != 0;  // initial gs_set_graph_mode
-        if (const char* e = std::getenv("GS_EXP_MODE")) r->hw_exp = std::atoi(e) != 0;  // initial gs_set_exp_mode
+        if (const char* e = std::getenv("GS_EXP_MODE")) r->exp_mode = std::min(2, std::max(0, std::atoi(e)));  // initial gs_set_exp_mode
+        if (const char* e = std::getenv("GS_BLEND_CONTRACTION")) r->contract = std::atoi(e) != 0;  // initial gs_set_blend_contraction
         if (const char* e = std::getenv("GS_BIN_SHIFT")) r->min_bin_shift = std::min(5, std::max(2, std::atoi(e)));  // default bin edge
         if (const char* e = std::getenv("GS_SORT_PATH")) {  // initial gs_set_sort_path, for hosts that cannot call it (the viewer)
             const int mode = std::atoi(e);
@@ -1347,9 +1350,18 @@ int gs_set_sort_path(gs_renderer* r, int mode) {
 int gs_set_exp_mode(gs_renderer* r, int mode) {
     return guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "renderer is null");
-        if (mode < 0 || mode > 1) throw Error(GS_ERR_INVALID, "exp mode must be 0 (pipeline-defined, exact) or 1 (hardware v_exp_f32)");
+        if (mode < 0 || mode > 2)
+            throw Error(GS_ERR_INVALID, "exp mode must be 0 (pipeline polynomial), 1 (hardware v_exp_f32) or 2 (libm's expf in binary64)");
         r->drain();
-        r->hw_exp = mode == 1;
+        r->exp_mode = mode;
+    });
+}
+
+int gs_set_blend_contraction(gs_renderer* r, int enabled) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "renderer is null");
+        r->drain();
+        r->contract = enabled != 0;
     });
 }
 

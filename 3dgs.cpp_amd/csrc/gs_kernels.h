@@ -139,7 +139,9 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s);  // k_bin_
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
-                  Counters* host_counters /* pinned, nullable: *host_counters = *counters */, bool hw_exp,
+                  Counters* host_counters /* pinned, nullable: *host_counters = *counters */,
+                  int exp_mode /* 0 pipeline polynomial, 1 v_exp_f32, 2 libm's expf restated in binary64 */,
+                  bool contract /* the pipeline's FMA contractions of render.comp:66,87 (default) or none */,
                   const FrameParams* fp, hipStream_t s);
 
 }  // namespace gs

@@ -1945,6 +1945,40 @@ __device__ __forceinline__ float gs_exp_blend(float x) {
     return __uint_as_float(__float_as_uint(p) + (__float_as_uint(tm) << 23));
 }
 
+// exp() as glibc's expf evaluates it (glibc >= 2.27, sysdeps/ieee754/flt-32/e_expf.c = ARM optimized-routines expf: x 32/ln2 split
+// into k + r in binary64, 2^(k/32) from a 32-entry table, a cubic in r, ONE rounding to binary32 at the end), operation by
+// operation in binary64 with the fused operations of the x86-64 FMA build -- so that the blend can be bit-identical to the
+// reference's shader text compiled for the CPU (the test suite's checker), whose exp() is libm's.  Restated from the published algorithm,
+// the table generated (2^(i/32) correctly rounded, exponent pre-subtracted), and PINNED by tests/test_expf_libm.py: equal to
+// this container's libm expf on every binary32 in [-87, 0] (1.1e9 values).  10 binary64 operations (half rate on gfx950) + one
+// LDS read: ~23 issue slots against 10 for the polynomial.  Valid for the blend's range (x <= 0, results used for x >= -7).
+__device__ const uint64_t kExpfTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+__device__ __forceinline__ float gs_expf_libm(float x, const uint2* __restrict__ tab /* LDS copy of kExpfTab */) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0, C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    const double xd = (double)x;
+    double kd = __builtin_fma(InvLn2N, xd, SHIFT);          // k = round(x 32/ln2) in the low mantissa bits
+    const uint32_t ki = (uint32_t)__double_as_longlong(kd);
+    kd = kd - SHIFT;
+    const double r = __builtin_fma(InvLn2N, xd, -kd);
+    uint2 t = tab[ki & 31u];
+    t.y += ki << 15;                                        // t += ki << 47: the exponent of 2^(k/32)
+    const double sc = __longlong_as_double((long long)(((uint64_t)t.y << 32) | t.x));
+    const double z = __builtin_fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(z, r2, y);
+    y = y * sc;
+    return (float)y;
+}
+
 struct BlendEntry {
     float4 co;  // c00 c01 c11 opacity
     float4 uv;  // u v r g
@@ -1958,7 +1992,10 @@ __device__ __forceinline__ void blend_fetch(BlendEntry& e, uint32_t g, const Att
     e.b = r->b_depth_r.x;
 }
 
-template <bool HW_EXP>
+// CONTRACT: the pipeline's three contractions of render.comp:66,87 (default) or the uncontracted reading, one rounding per
+// operation exactly as the shader is written -- what the reference's text compiled for the CPU evaluates (gs_set_blend_contraction).
+// EXP: 0 the pipeline-defined polynomial (gs_exp_blend), 1 the hardware's v_exp_f32, 2 libm's expf restated (gs_expf_libm).
+template <int EXP, bool CONTRACT>
 __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ sorted_gid,
                                                  const uint32_t* __restrict__ tile_order,
@@ -1975,8 +2012,16 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     // wave-private slabs (no cross-wave sharing, no barriers), three planes of 64 float4 per wave: {c00 c01 c11 o} {u v r g} {b, pmin, -, -}.  Plane-major keeps the staging
     // ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets serve the reads
     __shared__ float4 s_rec[4][3][WAVE];
+    __shared__ uint2 s_exptab[EXP == 2 ? 4 : 1][32];  // wave-private copies of kExpfTab (no workgroup barrier in this kernel)
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    if (EXP == 2) {
+        if (lane < 32) {
+            const uint64_t v = kExpfTab[lane];
+            s_exptab[w][lane] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     // last kernel of the frame: hand V, D, E1 and the overflow flag to the host (pinned memory; visible to it once
     // the frame's completion event, which carries the system-scope release, has fired) -- no copy node in the stream
     if (host_counters && blockIdx.x == 0 && tid == 0) *host_counters = *counters;
@@ -2065,26 +2110,41 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                 const float dx = uv.x - fx;
                 const float dy = uv.y - fy;
                 // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
-                const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);        // FMA  (= -0.5 * the shader's sum)
-                const float power = __builtin_fmaf(co.y * dx, dy, s);                 // FMA
+                float power;
+                if (CONTRACT) {
+                    const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);    // FMA  (= -0.5 * the shader's sum)
+                    power = __builtin_fmaf(co.y * dx, dy, s);                         // FMA
+                } else {  // -0.5 * (c00 dx dx + c11 dy dy) - c01 dx dy, every product and sum rounded (the conic is pre-scaled)
+                    const float s = co.x * dx * dx + co.z * dy * dy;
+                    power = s + co.y * dx * dy;
+                }
                 // power <= 0 is false for NaN: a NaN power skips the entry (the pipeline's definition)
                 const uint64_t m1 = alive & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                     __builtin_amdgcn_ballot_w64(!(power < bp.y));
                 if (m1 != 0) {
                     STAT_ADD(4, 1);                   // pairs reaching exp
                     STAT_ADD(5, __popcll(m1));        // lanes needing exp
-                    // :77.  HW_EXP: the hardware's v_exp_f32 (what a Vulkan driver emits for exp()); otherwise the
-                    // pipeline-defined polynomial that the oracle reproduces bit for bit
-                    const float ex = HW_EXP ? __builtin_amdgcn_exp2f(power * 1.44269502162933349609375f) : gs_exp_blend(power);
+                    // :77.  EXP 1: the hardware's v_exp_f32 (what a Vulkan driver emits for exp()); 2: libm's expf, what the
+                    // reference's text compiled for the CPU calls; 0: the pipeline-defined polynomial.  The oracle reproduces
+                    // 0 and 2 bit for bit
+                    const float ex = EXP == 1   ? __builtin_amdgcn_exp2f(power * 1.44269502162933349609375f)
+                                     : EXP == 2 ? gs_expf_libm(power, s_exptab[EXP == 2 ? w : 0])
+                                                : gs_exp_blend(power);
                     const float alpha = fminf(0.99f, co.w * ex);
                     const uint64_t m2 = m1 & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
                     const float test_T = T * (1 - alpha);
                     const uint64_t mk = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);  // :82-85 break
                     const bool upd = __builtin_amdgcn_inverse_ballot_w64(m2 & ~mk);
                     if (upd) {  // the accumulate runs under the exec mask: no selects
-                        c0 = __builtin_fmaf(uv.z * alpha, T, c0);  // :87  FMA
-                        c1 = __builtin_fmaf(uv.w * alpha, T, c1);
-                        c2 = __builtin_fmaf(bp.x * alpha, T, c2);
+                        if (CONTRACT) {
+                            c0 = __builtin_fmaf(uv.z * alpha, T, c0);  // :87  FMA
+                            c1 = __builtin_fmaf(uv.w * alpha, T, c1);
+                            c2 = __builtin_fmaf(bp.x * alpha, T, c2);
+                        } else {  // c += color * alpha * T
+                            c0 = c0 + uv.z * alpha * T;
+                            c1 = c1 + uv.w * alpha * T;
+                            c2 = c2 + bp.x * alpha * T;
+                        }
                         T = test_T;
                     }
 #if GS_BLEND_SALU_DIET
@@ -2115,20 +2175,32 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     }
 }
 
+template <int EXP, bool CONTRACT>
+static void launch_blend_as(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
+                            uint32_t width, uint32_t height, uint32_t tx, uint32_t ty, float* rgba, uint8_t* bgra,
+                            const Counters* counters, Counters* host_counters, const FrameParams* fp, hipStream_t s) {
+    hipLaunchKernelGGL((k_blend<EXP, CONTRACT>), dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
+                       sorted_gid, tile_order, av.rec, width, height, tx, reinterpret_cast<float4*>(rgba),
+                       reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp);
+}
+
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
-                  Counters* host_counters, bool hw_exp, const FrameParams* fp, hipStream_t s) {
+                  Counters* host_counters, int exp_mode, bool contract, const FrameParams* fp, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
-    if (hw_exp)
-        hipLaunchKernelGGL(k_blend<true>, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           sorted_gid, tile_order, av.rec, width, height, tx,
-                           reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp);
-    else
-        hipLaunchKernelGGL(k_blend<false>, dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           sorted_gid, tile_order, av.rec, width, height, tx,
-                           reinterpret_cast<float4*>(rgba), reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp);
+#define GS_BLEND_CASE(E, C)                                                                                              \
+    if (exp_mode == E && contract == C)                                                                                  \
+        return launch_blend_as<E, C>(ranges, sorted_gid, tile_order, av, width, height, tx, ty, rgba, bgra, counters,    \
+                                     host_counters, fp, s)
+    GS_BLEND_CASE(0, true);
+    GS_BLEND_CASE(0, false);
+    GS_BLEND_CASE(1, true);
+    GS_BLEND_CASE(1, false);
+    GS_BLEND_CASE(2, true);
+    GS_BLEND_CASE(2, false);
+#undef GS_BLEND_CASE
 }
 
 #ifdef GS_BLEND_STATS

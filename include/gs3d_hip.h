@@ -189,12 +189,26 @@ int gs_set_frames_in_flight(gs_renderer* r, int frames);
  *                 once the bins have fitted again for 32 frames).
  * The GS_STAGE_DEPTH_ORDER tap exists on path 1 only. */
 int gs_set_sort_path(gs_renderer* r, int mode);
-/* exp() of render.comp:77, which GLSL leaves to the implementation (3 + 2|x| ULP):
- *   0  (default) the pipeline-defined polynomial: every pixel reproducible bit for bit on a CPU (the parity oracle);
- *   1  the hardware's v_exp_f32 (what a Vulkan driver emits for exp()): ~10 % faster blend, pixels within a few
- *      ULP of mode 0 apart from rare alpha-threshold flips (render.comp:78), still <= 1e-4 of the reference elsewhere.
+/* The blend's arithmetic (render.comp:61-98).  The DEFAULT is the reference's shader text read literally and evaluated the
+ * way its CPU compilation (the checker the tests pin this library to) evaluates it: every product and sum of :66 and
+ * :87 rounded on its own, exp() of :77 = libm's expf.  In that mode the frame is BIT-IDENTICAL to render.comp compiled for
+ * a CPU, on any scene (tests/test_gpu_blend_modes.py, test_gpu_full_size.py).  Two opt-in relaxations, both inside what
+ * GLSL grants an implementation, buy speed (config B: 3.3 k -> 4.1 k frames/s with both):
+ *
+ * gs_set_exp_mode -- exp() of render.comp:77, which GLSL leaves to the implementation (3 + 2|x| ULP):
+ *   2  (default) glibc's expf algorithm restated in binary64 (x 32/ln2 = k + r, 2^(k/32) from a 32-entry table, a cubic,
+ *      one rounding to binary32): bit-equal to libm on every binary32 <= 0, ten half-rate binary64 operations per pair;
+ *   0  the pipeline-defined binary32 polynomial (< 2 ULP): reproducible bit for bit on a CPU (the oracle's fast reading),
+ *      pixels within ULP noise of mode 2 except where an alpha sits within rounding of render.comp:78's 1/255 cut;
+ *   1  the hardware's v_exp_f32 (what a Vulkan driver emits for exp()): fastest, not reproducible on a CPU.
  * GS_EXP_MODE sets the initial mode for hosts that cannot call this (the viewer). */
 int gs_set_exp_mode(gs_renderer* r, int mode);
+/* gs_set_blend_contraction -- render.comp:66 and :87 hold three multiply-adds that GLSL lets a compiler contract into FMAs
+ * (the shader has no `precise`).  0 (default): as written, one rounding per operation; 1: the three contractions (5 VALU
+ * instructions per blended pair fewer).  The two differ by ULP noise on benign scenes and by up to 3e-3 on scenes of thin,
+ * long splats, where `power` is a difference of much larger terms.
+ * GS_BLEND_CONTRACTION sets the initial mode. */
+int gs_set_blend_contraction(gs_renderer* r, int enabled);
 /* Replay frames as ONE captured HIP graph each (answers VulkanContext.h:6 / Renderer.cpp:391-395, 532-717: the
  * reference re-records its render command buffer every frame because dispatch sizes depend on D; here every grid is
  * data-independent, so a frame's launches are captured once per configuration -- resolution, depth-order level,

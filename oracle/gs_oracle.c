@@ -99,6 +99,86 @@ float gso_exp(float x) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* exp() as libm evaluates it.  The reference's shader text compiled for the   */
+/* CPU (oracle/_ref) calls libm's expf for render.comp:77; glibc >= 2.27       */
+/* (sysdeps/ieee754/flt-32/e_expf.c, from ARM's optimized-routines, 2017) is   */
+/* NOT in /root/reference, so its published algorithm is restated here:        */
+/*   x*32/ln2 = k + r in binary64 (round-to-nearest by the 0x1.8p52 shift),    */
+/*   2^(k/32) from a 32-entry table with the exponent added to the bit         */
+/*   pattern, 2^(r/32) ~ C0 r^3 + C1 r^2 + C2 r + 1, one rounding to binary32. */
+/* The fused operations are those of glibc's x86-64 FMA build (the ifunc       */
+/* variant this container and the GPU boxes select).  The table is generated   */
+/* (2^(i/32) correctly rounded, minus i << 47).  tests/test_expf_libm.py pins  */
+/* it: bit-equal to this machine's expf on every binary32 in [-87, 0].         */
+/* The HIP kernels evaluate the same ten binary64 operations (gs_expf_libm).   */
+/* Domain: x <= 0 (the blend never asks for more: power <= 0); below          */
+/* -0x1.9fe368p6 (-103.97) the result is 0 like glibc's underflow branch.      */
+/* ------------------------------------------------------------------------- */
+const uint64_t k_expf_tab_export[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+/* the table, readable from the tests (tests/test_expf_libm.py regenerates it) */
+#define k_expf_tab k_expf_tab_export
+float gso_expf_libm(float x) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0,
+                 C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    if (x < -0x1.9fe368p6f) return 0.0f; /* glibc: __math_uflowf */
+    const double xd = (double)x;
+    double kd = fma(InvLn2N, xd, SHIFT);
+    uint64_t ki;
+    memcpy(&ki, &kd, 8);
+    kd = kd - SHIFT;
+    const double r = fma(InvLn2N, xd, -kd);
+    uint64_t t = k_expf_tab[ki & 31u] + (ki << 47);
+    double sc;
+    memcpy(&sc, &t, 8);
+    const double z = fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = fma(C2, r, 1.0);
+    y = fma(z, r2, y);
+    y = y * sc;
+    return (float)y;
+}
+/* bulk form for the exhaustive pin: out[i] = gso_expf_libm(bits -> float of first + i) */
+void gso_expf_libm_range(uint32_t first_bits, uint64_t count, float* out) {
+#pragma omp parallel for
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        uint32_t b = first_bits + (uint32_t)i;
+        float x;
+        memcpy(&x, &b, 4);
+        out[i] = gso_expf_libm(x);
+    }
+}
+/* count of binary32 values with bit patterns first_bits .. first_bits + count - 1 on which gso_expf_libm and this
+ * machine's libm expf differ (the pin itself, without moving 4 GB through Python) */
+uint64_t gso_expf_libm_mismatches(uint32_t first_bits, uint64_t count, uint32_t* first_bad_bits) {
+    uint64_t bad = 0;
+    uint32_t first_bad = 0xFFFFFFFFu;
+#pragma omp parallel for reduction(+ : bad) reduction(min : first_bad)
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        uint32_t b = first_bits + (uint32_t)i, ua, ub;
+        float x, a, c;
+        memcpy(&x, &b, 4);
+        a = gso_expf_libm(x);
+        c = expf(x);
+        memcpy(&ua, &a, 4);
+        memcpy(&ub, &c, 4);
+        if (ua != ub) {
+            ++bad;
+            if (b < first_bad) first_bad = b;
+        }
+    }
+    if (first_bad_bits) *first_bad_bits = first_bad;
+    return bad;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Camera: Renderer::updateUniforms, src/Renderer.cpp:719-754 (+ glm 1.0.0)   */
 /* ------------------------------------------------------------------------- */
 static void mat4_identity(float* m) {
@@ -647,12 +727,16 @@ void gso_tile_boundary(const uint64_t* keys, uint64_t d, uint32_t* boundaries, u
  * (oracle/_ref, -ffp-contract=off) evaluates: with it, oracle and reference text differ in exp() alone, for any scene.
  * The two readings agree to ULP noise unless `power` is a difference of much larger terms (thin, long splats far from
  * their centre), where one rounding more or less moves alpha by ~2^-24 x |terms| (tests/test_oracle_vs_ref.py). */
-static int g_contract = 1;
+static int g_contract = 0; /* default: the reference text's reading */
 void gso_set_contraction(int on) { g_contract = on != 0; }
+/* which exp() render.comp:77 gets: 0 the pipeline polynomial gso_exp (the product's exp mode 0), 2 libm's expf restated
+ * (gso_expf_libm: the product's exp mode 2 and, by the pin, what oracle/_ref evaluates) */
+static int g_exp_mode = 2; /* default: what the reference text compiled for the CPU calls */
+void gso_set_exp_mode(int mode) { g_exp_mode = mode == 2 ? 2 : 0; }
 
 void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const uint32_t* payload,
                 uint32_t width, uint32_t height, float* rgba) {
-    const int contract = g_contract;
+    const int contract = g_contract, exp_libm = g_exp_mode == 2;
     const uint32_t tiles_width = (width + 16 - 1) / 16;
     const uint32_t tiles_height = (height + 16 - 1) / 16;
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
@@ -684,7 +768,7 @@ void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const u
                          * the comparison and the following exp(NaN) undefined; the pipeline
                          * defines "no contribution". */
                         if (power > 0.0f || power != power) continue;
-                        float alpha = fminf(0.99f, co[3] * gso_exp(power)); /* :77 */
+                        float alpha = fminf(0.99f, co[3] * (exp_libm ? gso_expf_libm(power) : gso_exp(power))); /* :77 */
                         if (alpha < 1.0f / 255.0f) continue;
                         float test_T = T * (1 - alpha);
                         if (test_T < 0.0001f) break; /* :82-85 */
@@ -736,11 +820,39 @@ static inline __m256 gso_exp8(__m256 x) {
     return _mm256_castsi256_ps(pb);
 }
 
+/* gso_expf_libm, eight lanes: the same ten binary64 operations per lane (two __m256d halves) */
+static inline __m128 gso_expf_libm4(__m128 x) {
+    const __m256d InvLn2N = _mm256_set1_pd(0x1.71547652b82fep+0 * 32.0), SHIFT = _mm256_set1_pd(0x1.8p+52);
+    const __m256d C0 = _mm256_set1_pd(0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0), C1 = _mm256_set1_pd(0x1.ebfce50fac4f3p-3 / 32.0 / 32.0),
+                  C2 = _mm256_set1_pd(0x1.62e42ff0c52d6p-1 / 32.0);
+    const __m256d xd = _mm256_cvtps_pd(x);
+    __m256d kd = _mm256_fmadd_pd(InvLn2N, xd, SHIFT);
+    const __m256i ki = _mm256_castpd_si256(kd);
+    kd = _mm256_sub_pd(kd, SHIFT);
+    const __m256d r = _mm256_fmsub_pd(InvLn2N, xd, kd); /* fma(InvLn2N, xd, -kd) */
+    const __m256i idx = _mm256_and_si256(ki, _mm256_set1_epi64x(31));
+    __m256i t = _mm256_i64gather_epi64((const long long*)k_expf_tab, idx, 8);
+    t = _mm256_add_epi64(t, _mm256_slli_epi64(ki, 47));
+    const __m256d sc = _mm256_castsi256_pd(t);
+    const __m256d z = _mm256_fmadd_pd(C0, r, C1);
+    const __m256d r2 = _mm256_mul_pd(r, r);
+    __m256d y = _mm256_fmadd_pd(C2, r, _mm256_set1_pd(1.0));
+    y = _mm256_fmadd_pd(z, r2, y);
+    y = _mm256_mul_pd(y, sc);
+    __m128 res = _mm256_cvtpd_ps(y);
+    /* x < -0x1.9fe368p6: 0 (glibc's underflow branch); false for NaN */
+    return _mm_andnot_ps(_mm_cmp_ps(x, _mm_set1_ps(-0x1.9fe368p6f), _CMP_LT_OQ), res);
+}
+static inline __m256 gso_expf_libm8(__m256 x) {
+    return _mm256_set_m128(gso_expf_libm4(_mm256_extractf128_ps(x, 1)), gso_expf_libm4(_mm256_castps256_ps128(x)));
+}
+
 void gso_render_simd(const gso_vertex_attr* attr, const uint32_t* boundaries, const uint32_t* payload,
                      uint32_t width, uint32_t height, float* rgba) {
     const uint32_t tiles_width = (width + 16 - 1) / 16;
     const uint32_t tiles_height = (height + 16 - 1) / 16;
     const __m256 lane = _mm256_setr_ps(0, 1, 2, 3, 4, 5, 6, 7);
+    const int contract = g_contract, exp_libm = g_exp_mode == 2;
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
     for (int64_t ty = 0; ty < (int64_t)tiles_height; ++ty)
         for (int64_t tx = 0; tx < (int64_t)tiles_width; ++tx) {
@@ -762,23 +874,38 @@ void gso_render_simd(const gso_vertex_attr* attr, const uint32_t* boundaries, co
                         const float* co = a->conic_opacity;
                         const __m256 dx = _mm256_sub_ps(_mm256_set1_ps(a->uv[0]), fpx);
                         const __m256 dy = _mm256_sub_ps(_mm256_set1_ps(a->uv[1]), fpy);
-                        const __m256 s = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(co[2]), dy), dy,
-                                                         _mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(co[0]), dx), dx));
-                        const __m256 nb = _mm256_xor_ps(_mm256_mul_ps(_mm256_set1_ps(co[1]), dx), _mm256_set1_ps(-0.0f));
-                        const __m256 power = _mm256_fmadd_ps(nb, dy, _mm256_mul_ps(_mm256_set1_ps(-0.5f), s));
+                        __m256 power;
+                        if (contract) {
+                            const __m256 s = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(co[2]), dy), dy,
+                                                             _mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(co[0]), dx), dx));
+                            const __m256 nb = _mm256_xor_ps(_mm256_mul_ps(_mm256_set1_ps(co[1]), dx), _mm256_set1_ps(-0.0f));
+                            power = _mm256_fmadd_ps(nb, dy, _mm256_mul_ps(_mm256_set1_ps(-0.5f), s));
+                        } else { /* -0.5f * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy, as written */
+                            const __m256 s = _mm256_add_ps(_mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(co[0]), dx), dx),
+                                                           _mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(co[2]), dy), dy));
+                            power = _mm256_sub_ps(_mm256_mul_ps(_mm256_set1_ps(-0.5f), s),
+                                                  _mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(co[1]), dx), dy));
+                        }
                         /* !(power > 0 || power != power)  ==  power <= 0, ordered */
                         __m256 m = _mm256_and_ps(active, _mm256_cmp_ps(power, _mm256_setzero_ps(), _CMP_LE_OQ));
                         if (!_mm256_movemask_ps(m)) continue;
                         /* fminf(0.99f, x): the other operand when x is NaN */
-                        const __m256 alpha = _mm256_min_ps(_mm256_mul_ps(_mm256_set1_ps(co[3]), gso_exp8(power)),
+                        const __m256 alpha = _mm256_min_ps(_mm256_mul_ps(_mm256_set1_ps(co[3]), exp_libm ? gso_expf_libm8(power) : gso_exp8(power)),
                                                            _mm256_set1_ps(0.99f));
                         m = _mm256_andnot_ps(_mm256_cmp_ps(alpha, _mm256_set1_ps(1.0f / 255.0f), _CMP_LT_OQ), m);
                         const __m256 test_T = _mm256_mul_ps(T, _mm256_sub_ps(_mm256_set1_ps(1.0f), alpha));
                         const __m256 brk = _mm256_and_ps(m, _mm256_cmp_ps(test_T, _mm256_set1_ps(0.0001f), _CMP_LT_OQ));
                         const __m256 upd = _mm256_andnot_ps(brk, m);
-                        const __m256 n0 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[0]), alpha), T, c0);
-                        const __m256 n1 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[1]), alpha), T, c1);
-                        const __m256 n2 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[2]), alpha), T, c2);
+                        __m256 n0, n1, n2;
+                        if (contract) {
+                            n0 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[0]), alpha), T, c0);
+                            n1 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[1]), alpha), T, c1);
+                            n2 = _mm256_fmadd_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[2]), alpha), T, c2);
+                        } else { /* c += color * alpha * T */
+                            n0 = _mm256_add_ps(c0, _mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[0]), alpha), T));
+                            n1 = _mm256_add_ps(c1, _mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[1]), alpha), T));
+                            n2 = _mm256_add_ps(c2, _mm256_mul_ps(_mm256_mul_ps(_mm256_set1_ps(a->color_radii[2]), alpha), T));
+                        }
                         c0 = _mm256_blendv_ps(c0, n0, upd);
                         c1 = _mm256_blendv_ps(c1, n1, upd);
                         c2 = _mm256_blendv_ps(c2, n2, upd);

@@ -41,6 +41,9 @@ def lib():
         _LIB = C.CDLL(path)
         _LIB.gso_exp.restype = C.c_float
         _LIB.gso_exp.argtypes = [C.c_float]
+        _LIB.gso_expf_libm.restype = C.c_float
+        _LIB.gso_expf_libm.argtypes = [C.c_float]
+        _LIB.gso_expf_libm_mismatches.restype = C.c_uint64
         _LIB.gso_render_frame.restype = C.c_int
         _LIB.gso_load_ply.restype = C.c_int
         _LIB.gso_num_threads.restype = C.c_int
@@ -139,9 +142,57 @@ def render(attr, boundaries, payload, width, height, simd=False):
 
 
 def set_contraction(on):
-    """render(): True (default) = the pipeline's three FMA contractions; False = render.comp:66,87 uncontracted, as the
-    reference's shader text compiled for the CPU evaluates them (gso_set_contraction)."""
+    """render(): False (default) = render.comp:66,87 uncontracted, as the reference's shader text compiled for the CPU
+    evaluates them; True = the three FMA contractions of the product's fast blend (gso_set_contraction)."""
     lib().gso_set_contraction(C.c_int(int(bool(on))))
+
+
+def set_exp_mode(mode):
+    """render(): 2 (default) = libm's expf restated (gso_expf_libm), what the reference's shader text compiled for the
+    CPU calls; 0 = the pipeline polynomial gso_exp of the product's fast blend."""
+    lib().gso_set_exp_mode(C.c_int(int(mode)))
+
+
+class fast_reading:
+    """with oracle.fast_reading(): render() evaluates the product's opt-in FAST blend -- the three FMA contractions GLSL
+    permits in render.comp:66,87 and the pipeline-defined polynomial exp (gs_set_blend_contraction(1) + gs_set_exp_mode(0)).
+    Outside of it render() is the reference reading: uncontracted, libm's expf -- operation for operation what the
+    reference's text compiled for the CPU (oracle/_ref) evaluates, and the product's default."""
+
+    def __enter__(self):
+        set_contraction(True)
+        set_exp_mode(0)
+
+    def __exit__(self, *a):
+        set_contraction(False)
+        set_exp_mode(2)
+
+
+class reading:
+    """with oracle.reading(contract, exp_mode): any combination (exp_mode 0 or 2)."""
+
+    def __init__(self, contract, exp_mode):
+        self.c, self.e = contract, exp_mode
+
+    def __enter__(self):
+        set_contraction(self.c)
+        set_exp_mode(self.e)
+
+    def __exit__(self, *a):
+        set_contraction(False)
+        set_exp_mode(2)
+
+
+def expf_libm(x):
+    x = np.asarray(x, np.float32)
+    return np.array([lib().gso_expf_libm(float(v)) for v in x.ravel()], np.float32).reshape(x.shape)
+
+
+def expf_libm_mismatches(first_bits, count):
+    """(# of binary32 bit patterns in [first_bits, first_bits + count) where gso_expf_libm != this machine's expf, first)"""
+    bad = C.c_uint32(0)
+    n = lib().gso_expf_libm_mismatches(C.c_uint32(first_bits), C.c_uint64(count), C.byref(bad))
+    return int(n), int(bad.value)
 
 
 def set_simd_blend(on):

@@ -46,6 +46,9 @@ def compare_stages(pkg, rend, u, ref):
 
 
 # ---------------------------------------------------------------- image comparison across exp() implementations
+# The DEFAULT blend (product and oracle) is bit-identical to the reference text compiled for the CPU: those comparisons
+# are assert_array_equal on the bit patterns and need none of this.  What follows serves the OPT-IN fast modes
+# (gs_set_exp_mode 0 / 1, gs_set_blend_contraction 1), whose difference from the reference text is characterised here:
 # render.comp:77 leaves exp() to the implementation (GLSL: 3 + 2|x| ULP) and :66/:87 may or may not be contracted
 # to FMAs.  Two conformant evaluations of the same lists therefore agree to a few ULP per pixel -- except where an
 # entry's alpha falls within rounding of the 1/255 cut (render.comp:78), its power within rounding of 0 (:68), or
@@ -101,10 +104,22 @@ def classify_pixel(attr, boundaries, payload, width, px, py):
     return near
 
 
-def compare_images(img, ref_img, ref, width, label=""):
-    """img vs ref_img (both H x W x >=3), lists taken from `ref` (attr, boundaries, sorted_payload).
-    Asserts: every pixel differing by more than ULP_NOISE is an explained threshold flip, and there are at most
-    max(3, 1e-5 * P) of them.  Returns (max diff over unflipped pixels, list of flipped pixels)."""
+def assert_images_identical(img, ref_img, label=""):
+    """Bit-for-bit equality of two fp32 images (the default blend against the reference text / the oracle)."""
+    a, b = np.ascontiguousarray(img, np.float32).view(np.uint32), np.ascontiguousarray(ref_img, np.float32).view(np.uint32)
+    if not np.array_equal(a, b):
+        bad = np.argwhere((a != b).any(axis=-1))
+        d = np.abs(img.astype(np.float64) - ref_img).max()
+        raise AssertionError(f"{label}: {len(bad)} pixel(s) differ in their bit patterns (max |d| {d:.3g}), first at (x, y) = "
+                             f"({bad[0][1]}, {bad[0][0]})")
+
+
+def compare_images(img, ref_img, ref, width, label="", max_flips=None):
+    """FAST-MODE comparison.  img vs ref_img (both H x W x >=3), lists taken from `ref` (attr, boundaries, sorted_payload).
+    Asserts: every pixel differing by more than ULP_NOISE is an explained threshold flip (or within the cancellation bound
+    of a contracted `power`), and there are at most max_flips of them: callers of the named configs pass the count observed
+    for their case + 1; sweeps leave it None = max(3, 3 per 1e8 (pixel, entry) evaluations) (config B: 6 in 1.25e9).
+    Returns (max diff over unflipped pixels, list of flipped pixels)."""
     d = np.abs(img[..., :3].astype(np.float64) - ref_img[..., :3]).max(axis=2)
     ys, xs = np.nonzero(d > ULP_NOISE)
     flips = []
@@ -116,10 +131,10 @@ def compare_images(img, ref_img, ref, width, label=""):
                                       f"and a cancellation bound of {near['cancel']:.3g}: {near}")
         if flipped and not cancelled:
             flips.append((px, py, float(d[py, px]), near))
-    # how many pixels may sit on a cut: a few per million pixels, and no more than ~2 per ten million (pixel, entry)
-    # evaluations (config B: 6 flips for ~1e9 of them) -- dense scenes of large splats evaluate thousands of entries a pixel
-    pairs = 256.0 * len(ref["sorted_payload"])
-    assert len(flips) <= max(3, 1e-5 * d.size, 2e-7 * pairs), f"{label}: {len(flips)} threshold-flip pixels"
+    if max_flips is None:
+        max_flips = max(3, int(3e-8 * 256.0 * len(ref["sorted_payload"])))
+    assert len(flips) <= max_flips, f"{label}: {len(flips)} threshold-flip pixels (allowed {max_flips}): " \
+                                    f"{[(x, y, round(dd, 6)) for x, y, dd, _ in flips]}"
     assert d.max() <= 2.0 / 255.0 * max(1.0, float(np.abs(ref_img[..., :3]).max()))
     rest = d.copy()
     rest[ys, xs] = 0

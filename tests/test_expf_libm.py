@@ -1,0 +1,56 @@
+"""Pins gso_expf_libm -- glibc's expf algorithm restated in binary64 (oracle/gs_oracle.c; the HIP blend's gs_expf_libm
+performs the same ten binary64 operations) -- to THIS MACHINE'S libm, exhaustively.
+
+Why it matters: the reference's shader text compiled for the CPU (oracle/_ref) evaluates render.comp:77's exp() with
+libm's expf.  With exp() identical on every input the blend can be, and is, bit-identical to the reference text
+(tests/test_oracle_vs_ref.py on the CPU, tests/test_gpu_blend_modes.py and test_gpu_full_size.py on the GPU).
+
+glibc's expf (sysdeps/ieee754/flt-32/e_expf.c since 2.27) is third-party code absent from /root/reference: the
+algorithm is restated from its published form (ARM optimized-routines, 2017), the 32-entry table is GENERATED below and
+compared with the one compiled into the oracle, and the result is checked against libm on every binary32 the blend
+can ask for (power <= 0: 2 139 095 041 values, a few seconds with OpenMP).
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+
+def _bits(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def test_equal_to_libm_on_every_nonpositive_binary32(oracle):
+    lo, hi = _bits(-0.0), _bits(float("-inf"))
+    bad, first = oracle.expf_libm_mismatches(lo, hi - lo + 1)
+    assert bad == 0, f"{bad} mismatches against libm expf, first at bits {first:#x}"
+
+
+def test_spot_values_and_table(oracle):
+    assert oracle.expf_libm(np.float32(0.0)) == 1.0 and oracle.expf_libm(np.float32(-0.0)) == 1.0
+    assert oracle.expf_libm(np.float32(-1000.0)) == 0.0 and oracle.expf_libm(np.float32(-np.inf)) == 0.0
+    x = np.linspace(-8, 0, 4001).astype(np.float32)
+    e = oracle.expf_libm(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    ulp = np.abs(e - ref) / np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert ulp.max() <= 0.502  # glibc's stated bound; correctly rounded in all but ~0.2 % of the cases
+    # the table: 2^(i/32) correctly rounded to binary64, with i << 47 subtracted from the bit pattern.  exp2(i/32) in
+    # binary64 (numpy -> libm exp2, itself < 1 ULP) may be off by one in the last place: recompute exactly with fractions
+    from fractions import Fraction
+    lib = oracle.lib()
+    tab = (C.c_uint64 * 32).in_dll(lib, "k_expf_tab_export")
+    for i in range(32):
+        # correctly rounded 2^(i/32): find the binary64 y with y^32 closest to 2^i by exact rational comparison
+        approx = float(2.0 ** (i / 32.0))
+        cands = [np.nextafter(approx, 0), approx, np.nextafter(approx, 4)]
+        target = Fraction(2) ** i
+
+        def err(c):  # |c - 2^(i/32)| is monotone in |c^32 - 2^i| near the root
+            return abs(Fraction(float(c)) ** 32 - target)
+        best = min(cands, key=err)
+        # the rounding boundary: best must beat the midpoints to its neighbours
+        for nb in (np.nextafter(best, 0), np.nextafter(best, 4)):
+            mid = (Fraction(float(best)) + Fraction(float(nb))) / 2
+            assert (mid ** 32 < target) == (nb < best), i
+        bits = struct.unpack("<Q", struct.pack("<d", float(best)))[0]
+        assert tab[i] == (bits - (i << 47)) & 0xFFFFFFFFFFFFFFFF, i

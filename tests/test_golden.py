@@ -2,8 +2,8 @@
 
 Every output in the file was computed by the reference's own shader text compiled for the CPU (oracle/_ref); the
 restated oracle and the HIP path must reproduce it: bit for bit in cov3D, the visible VertexAttribute records,
-tiles_overlap, the sorted payload and the tile boundaries; within 5e-6 in the image (render.comp's exp() is libm's
-there, the pipeline-defined polynomial here; the north-star bound is 1e-4).
+tiles_overlap, the sorted payload, the tile boundaries AND the image (render.comp's exp() is libm's there; the oracle and
+the HIP blend restate that function in binary64 and evaluate :66,87 uncontracted, like the CPU compilation).
 """
 import os
 
@@ -11,7 +11,6 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_a1200.npz")
-IMAGE_TOL = 5e-6  # a few ULP of exp() per term, accumulated over a pixel's list; measured 1.8e-6
 
 
 @pytest.fixture(scope="module")
@@ -40,7 +39,7 @@ def test_oracle_reproduces_golden(oracle, gold):
     np.testing.assert_array_equal((st["sorted_keys"] >> np.uint64(32)).astype(np.uint32), gold["sorted_tile"])
     np.testing.assert_array_equal(st["sorted_payload"], gold["sorted_payload"])
     np.testing.assert_array_equal(st["boundaries"], gold["boundaries"])
-    assert np.abs(st["image"][..., :3] - gold["image"]).max() <= IMAGE_TOL
+    np.testing.assert_array_equal(st["image"][..., :3].view(np.uint32), gold["image"].view(np.uint32))
 
 
 @pytest.mark.gpu
@@ -59,6 +58,7 @@ def test_hip_reproduces_golden(pkg, gpu, gold):
     np.testing.assert_array_equal(rend.stage("depth")[vis].view(np.uint32), va["depth"].view(np.uint32))
     np.testing.assert_array_equal(rend.stage("uv_rg").reshape(-1, 4)[vis][:, :2].view(np.uint32),
                                   np.ascontiguousarray(va["uv"]).view(np.uint32))
+    np.testing.assert_array_equal(rend.stage("sorted_tile"), gold["sorted_tile"])
     np.testing.assert_array_equal(rend.stage("sorted_gid"), gold["sorted_payload"])
     np.testing.assert_array_equal(rend.stage("ranges", u), gold["boundaries"])
-    assert np.abs(img[..., :3] - gold["image"]).max() <= IMAGE_TOL
+    np.testing.assert_array_equal(np.ascontiguousarray(img[..., :3]).view(np.uint32), gold["image"].view(np.uint32))

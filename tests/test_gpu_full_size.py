@@ -8,7 +8,7 @@ instance multiset equals sum(tiles_overlap), re-rendering is deterministic.
 import numpy as np
 import pytest
 
-from helpers import compare_images
+from helpers import assert_images_identical, compare_images
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +52,25 @@ def structural_checks(rend, u, n_tiles):
     return st
 
 
+def against_the_reference_text(label, rend, u, img, ref, w, h, max_flips=None):
+    """The same frame against the reference's own shader text (oracle/_ref): the lists are the oracle's, which
+    tests/test_oracle_vs_ref.py shows equal to the reference text's (bit for bit, B at full size included); the blend is
+    render.comp itself, compiled for the CPU.  The default blend must be BIT-IDENTICAL; the opt-in fast blend (polynomial
+    exp + contractions) is measured against it: max |d| away from render.comp's thresholds and the listed flip pixels."""
+    gsref = _ref_lib()
+    assert gsref is not None, "oracle/_ref did not travel to this box: the parity gate against the reference text cannot run"
+    rimg = gsref.render(ref["attr"], ref["boundaries"], ref["sorted_payload"], w, h)
+    assert_images_identical(img, rimg, label=f"{label}: default blend vs render.comp")
+    rend.set_fast_blend(True)
+    fast, _ = rend.render_host(u)
+    rend.set_fast_blend(False)
+    rest, flips = compare_images(fast, rimg, ref, w, label=f"{label}: fast blend vs render.comp", max_flips=max_flips)
+    d = np.abs(fast[..., :3].astype(np.float64) - rimg[..., :3]).max(axis=2)
+    print(f"{label} vs render.comp compiled for the CPU: default blend bit-identical ({img.shape[1]}x{img.shape[0]}); "
+          f"fast blend max|d| {d.max():.3g}, off-threshold {rest:.3g}, {int((d > 1e-4).sum())} px > 1e-4, threshold-flip pixels "
+          f"{[(x, y, round(dd, 6)) for x, y, dd, _ in flips]}")
+
+
 def _ref_lib():
     import __graft_entry__ as entry
     r = entry.load_ref()
@@ -86,13 +105,7 @@ def test_full_size_config(pkg, oracle, gpu, name, n, w, h):
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
     print(f"config {name}: N={n} V={st.num_visible} D={st.num_instances} max|rgb-oracle|={err:.3g} "
           f"gpu {st.ms_total:.3f} ms (pre {st.ms_preprocess:.3f} sort {st.ms_sort:.3f} blend {st.ms_render:.3f})")
-    if name == "B" and _ref_lib() is not None:
-        # the same frame against the reference's own shader text (oracle/_ref): the lists are the oracle's, which
-        # tests/test_oracle_vs_ref.py shows equal to the reference text's; the blend is render.comp itself
-        rimg = _ref_lib().render(ref["attr"], ref["boundaries"], ref["sorted_payload"], w, h)
-        rest, flips = compare_images(img, rimg, ref, w, label="HIP vs render.comp, config B")
-        print(f"config B vs render.comp (libm exp, no contraction): off-threshold max {rest:.3g}, "
-              f"{len(flips)} threshold-flip pixels {[(x, y, round(d, 6)) for x, y, d, _ in flips]}")
+    against_the_reference_text(f"config {name}", rend, u, img, ref, w, h)
 
 
 def test_config_d_eight_poses(pkg, oracle, gpu):
@@ -121,3 +134,5 @@ def test_config_d_eight_poses(pkg, oracle, gpu):
         assert err <= 1e-4, (k, err)
         np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
         print(f"config D pose {k}: V={st.num_visible} D={st.num_instances} max|rgb-oracle|={err:.3g}")
+        if k in (3, 6):  # two of the poses against render.comp itself as well
+            against_the_reference_text(f"config D pose {k}", rend, u, img, ref, w, h)

@@ -1,5 +1,7 @@
 """Seeded random sweep: scene size, splat size, opacity, framebuffer size, camera pose and field of view.
-Every case compares the per-tile lists, the ranges and the fp32 image with the oracle (bit-exact)."""
+Every case compares the per-tile lists, the ranges and the fp32 image with the oracle (bit-exact), the image with the
+reference's render.comp compiled for the CPU (oracle/_ref; bit-exact: the default blend), and the opt-in fast blend with
+the oracle's fast reading (bit-exact)."""
 import os
 
 import numpy as np
@@ -41,5 +43,15 @@ def test_random_case(pkg, oracle, gpu, seed):
     np.testing.assert_array_equal(rend.stage("ranges", u), ref["boundaries"])
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
     np.testing.assert_array_equal(bgra, oracle.pack_bgra8(ref["image"]))
+    import __graft_entry__ as entry
+    gsref = entry.load_ref()
+    if gsref.available() and n <= 60000:  # the scalar reference text is the slow side
+        rimg = gsref.render(ref["attr"], ref["boundaries"], ref["sorted_payload"], w, h)
+        np.testing.assert_array_equal(img.view(np.uint32), rimg.view(np.uint32))
+    rend.set_fast_blend(True)
+    fast, _ = rend.render_host(u)
+    with oracle.fast_reading():
+        want = oracle.render(ref["attr"], ref["boundaries"], ref["sorted_payload"], w, h)
+    np.testing.assert_array_equal(fast.view(np.uint32), want.view(np.uint32))
     rend.close()
     scene.close()

@@ -1,14 +1,16 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle, stage by stage and end to end.
 
 Tolerances: integer / index stages bit-exact; preprocess floats bit-exact (same operation order,
-no contraction); final fp32 RGB: max abs <= 1e-4 (BASELINE.json north_star), and in practice 0.
+no contraction); final fp32 RGB: max abs <= 1e-4 (BASELINE.json north_star), and in practice 0 -- the oracle's
+default reading is bit-identical to the reference's shader text compiled for the CPU (tests/test_oracle_vs_ref.py), and
+the product's default blend to both (the opt-in fast modes: tests/test_gpu_blend_modes.py).
 """
 import os
 
 import numpy as np
 import pytest
 
-from helpers import compare_images, compare_stages, oracle_frame
+from helpers import assert_images_identical, compare_stages, oracle_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -41,8 +43,7 @@ def test_config_a_stages_and_pixels(pkg, oracle, gpu):
 
 def test_hip_against_the_reference_shader_text(pkg, oracle, gpu):
     """HIP path vs oracle/_ref (the reference's .comp files compiled for the CPU) with no oracle in between:
-    config A and a rotated camera.  Integer stages and preprocess floats bit for bit, the image to ULP noise apart
-    from counted alpha-threshold pixels (different exp(): helpers.compare_images)."""
+    config A and a rotated camera.  Integer stages, preprocess floats AND the image bit for bit."""
     import __graft_entry__ as entry
     refl = entry.load_ref()
     if not refl.available():
@@ -62,9 +63,8 @@ def test_hip_against_the_reference_shader_text(pkg, oracle, gpu):
         img, _ = rend.render_host(u)
         np.testing.assert_array_equal(scene.download_cov3d().view(np.uint32), sr["cov3d"].view(np.uint32))
         compare_stages(pkg, rend, u, sr)
-        rest, flips = compare_images(img, sr["image"], sr, w, label=f"HIP vs reference text {w}x{h}")
-        print(f"HIP vs reference shader text, {n} @ {w}x{h}: off-threshold max {rest:.3g}, flips "
-              f"{[(x, y, round(d, 6)) for x, y, d, _ in flips]}")
+        assert_images_identical(img, sr["image"], label=f"HIP vs reference text {w}x{h}")
+        print(f"HIP vs reference shader text, {n} @ {w}x{h}: every stage and the image bit-identical")
 
 
 @pytest.mark.parametrize("w,h", [(200, 120), (33, 17), (16, 16), (1, 1), (641, 359), (4100, 2200), (7680, 4320),
@@ -619,25 +619,3 @@ def test_bins_are_refined_before_the_global_path(pkg, oracle, gpu, monkeypatch):
     assert st.max_bin_entries <= 16384
     compare_stages(pkg, rend, u, ref)
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
-
-
-def test_hardware_exp_mode_stays_within_the_north_star_bound(pkg, oracle, gpu):
-    """gs_set_exp_mode(1): the blend uses the hardware's v_exp_f32 (what a Vulkan driver emits for exp()).  Lists and
-    ranges are untouched; the image agrees with the exact mode to ULP noise except where an entry sits within rounding
-    of one of render.comp's thresholds (counted, re-traced in float64: helpers.compare_images) -- the same statement
-    the oracle satisfies against the reference's own shader text."""
-    for n, w, h, seed in [(10000, 256, 256, 0), (60000, 960, 540, 7)]:
-        rec = pkg.synth.synth_records(n, seed=seed, kind="A")
-        scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
-        np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
-        rend.set_exp_mode(1)
-        img_hw, _ = rend.render_host(u)
-        compare_stages(pkg, rend, u, ref)
-        rest, flips = compare_images(img_hw, ref["image"], ref, w, label=f"hardware exp {w}x{h}")
-        assert rest <= 1e-5
-        print(f"hardware exp, {n} @ {w}x{h}: off-threshold max {rest:.3g}, flips {[(x, y, round(d, 6)) for x, y, d, _ in flips]}")
-        rend.set_exp_mode(0)
-        img_back, _ = rend.render_host(u)
-        np.testing.assert_array_equal(img_back, img)
-        rend.close()
-        scene.close()

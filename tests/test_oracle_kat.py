@@ -201,7 +201,8 @@ def test_scan_sort_ranges_small(oracle):
 
 
 def test_exp_definition(oracle):
-    """gso_exp: exact at 0, < 2.5 ULP on the range the blend uses, inside GLSL's 3+2|x| ULP everywhere."""
+    """gso_exp (the fast reading's polynomial): exact at 0, < 2.5 ULP on the range the blend uses, inside GLSL's
+    3+2|x| ULP everywhere.  (The default reading's exp is gso_expf_libm: tests/test_expf_libm.py.)"""
     assert oracle.exp(np.float32(0.0)) == 1.0
     x = np.linspace(-8, 0, 20001).astype(np.float32)
     e = oracle.exp(x).astype(np.float64)
@@ -236,7 +237,10 @@ def test_simd_blend_is_bit_identical_to_the_scalar_checker(pkg, oracle):
             rec[::91, 55] = np.nan
         verts = oracle.activate_records(rec)
         st = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), w, h))
-        a = oracle.render(st["attr"], st["boundaries"], st["sorted_payload"], w, h)
-        b = oracle.render(st["attr"], st["boundaries"], st["sorted_payload"], w, h, simd=True)
-        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
-        np.testing.assert_array_equal(a.view(np.uint32), st["image"].view(np.uint32))
+        for contract, exp_mode in [(False, 2), (True, 0), (False, 0), (True, 2)]:  # the default reading first
+            with oracle.reading(contract, exp_mode):
+                a = oracle.render(st["attr"], st["boundaries"], st["sorted_payload"], w, h)
+                b = oracle.render(st["attr"], st["boundaries"], st["sorted_payload"], w, h, simd=True)
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+            if (contract, exp_mode) == (False, 2):
+                np.testing.assert_array_equal(a.view(np.uint32), st["image"].view(np.uint32))

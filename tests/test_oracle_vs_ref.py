@@ -7,17 +7,18 @@ per operation, libm exp).  On identical inputs the oracle must agree with it
   * bit for bit in cov3D, in every field of the visible VertexAttribute records (conic, opacity, rgb, radius, uv,
     depth, tile box), in tiles_overlap, the inclusive scan, the unsorted and sorted keys and payloads, the tile
     boundaries (integer stages AND preprocess floats: both evaluate the shader's operations in the shader's order);
-  * in the image to ULP noise (<= 1e-5; measured ~1e-6), except for a counted, listed handful of pixels where an entry
-    sits within rounding of one of render.comp's thresholds -- the two sides use different exp() implementations
-    (libm there, the pipeline-defined polynomial here; GLSL allows 3 + 2|x| ULP) and the oracle contracts the three
-    multiply-adds GLSL permits.  Every pixel above 1e-5 is re-traced in float64 and must be such a flip, or lie within
-    what one rounding of a cancelling `power` can move it by (helpers.classify_pixel).  With the oracle switched to the
-    uncontracted reading (gso_set_contraction(0)) only exp() differs, on any scene.
+  * AND IN THE IMAGE, bit for bit, in the oracle's default reading (render.comp:66,87 uncontracted, exp() = libm's expf
+    restated in binary64 and pinned by tests/test_expf_libm.py) -- which is also the product's default blend;
+  * in the oracle's FAST reading (the product's opt-in gs_set_exp_mode(0) + gs_set_blend_contraction(1): a binary32
+    polynomial exp and the three contractions GLSL permits) to ULP noise (<= 1e-5; measured ~1e-6), except for a counted,
+    listed handful of pixels where an entry sits within rounding of one of render.comp's thresholds.  Every pixel above
+    1e-5 is re-traced in float64 and must be such a flip, or lie within what one rounding of a cancelling `power` can
+    move it by (helpers.classify_pixel).
 """
 import numpy as np
 import pytest
 
-from helpers import compare_images
+from helpers import assert_images_identical, compare_images
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +42,13 @@ def assert_stage_parity(so, sr):
         np.testing.assert_array_equal(so[k], sr[k], err_msg=k)
 
 
-def run_case(pkg, oracle, ref, n, kind, w, h, seed, cam=None, mutate=None):
+def fast_image(oracle, st, w, h):
+    """The oracle's blend in the product's opt-in fast reading: contracted multiply-adds, polynomial exp."""
+    with oracle.fast_reading():
+        return oracle.render(st["attr"], st["boundaries"], st["sorted_payload"], w, h)
+
+
+def run_case(pkg, oracle, ref, n, kind, w, h, seed, cam=None, mutate=None, max_flips=None):
     rec = pkg.synth.synth_records(n, seed=seed, kind=kind)
     if mutate is not None:
         mutate(rec)
@@ -49,10 +56,12 @@ def run_case(pkg, oracle, ref, n, kind, w, h, seed, cam=None, mutate=None):
     u = oracle.camera_uniforms(cam if cam is not None else oracle.default_camera(), w, h)
     so, sr = oracle.stages(verts, u), ref.stages(verts, u)
     assert_stage_parity(so, sr)
-    rest, flips = compare_images(so["image"], sr["image"], sr, w, label=f"{kind}{n}@{w}x{h}")
-    assert (sr["image"][..., 3] == 1).all() and (so["image"][..., 3] == 1).all()
-    print(f"{kind}({n}) {w}x{h}: V={int((so['tiles'] > 0).sum())} D={len(so['keys'])} image max|d| off-threshold "
-          f"{rest:.3g}; threshold-flip pixels {[(x, y, round(d, 6)) for x, y, d, _ in flips]}")
+    assert_images_identical(so["image"], sr["image"], label=f"{kind}{n}@{w}x{h}: oracle (default reading) vs reference text")
+    assert (sr["image"][..., 3] == 1).all()
+    rest, flips = compare_images(fast_image(oracle, so, w, h), sr["image"], sr, w, label=f"{kind}{n}@{w}x{h}, fast reading",
+                                 max_flips=max_flips)
+    print(f"{kind}({n}) {w}x{h}: V={int((so['tiles'] > 0).sum())} D={len(so['keys'])} image == reference text bit for bit; fast "
+          f"reading: max|d| off-threshold {rest:.3g}, threshold-flip pixels {[(x, y, round(d, 6)) for x, y, d, _ in flips]}")
     return so, sr, flips
 
 
@@ -70,7 +79,7 @@ def test_config_a(pkg, oracle, ref):
 
 def test_config_b_full_size(pkg, oracle, ref):
     """BASELINE configs[1] at full size: S(1e6), 1920 x 1080, default camera (about 15 s on 8 cores)."""
-    so, sr, flips = run_case(pkg, oracle, ref, 1_000_000, "S", 1920, 1080, seed=0)
+    so, sr, flips = run_case(pkg, oracle, ref, 1_000_000, "S", 1920, 1080, seed=0, max_flips=7)  # observed: 6 of 2.07 M pixels
     assert len(so["keys"]) > 4_000_000
 
 
@@ -127,26 +136,14 @@ def test_config_e_geometry_and_density(pkg, oracle, ref):
     assert int(so["boundaries"].reshape(-1, 2)[:, 1].max()) == len(so["keys"]) or len(so["keys"]) > 0
 
 
-def strict_image(oracle, st, w, h):
-    """The oracle's blend with render.comp:66,87 evaluated UNCONTRACTED (gso_set_contraction(0)): the reading the
-    reference's shader text compiled for the CPU makes."""
-    oracle.set_contraction(False)
-    try:
-        return oracle.render(st["attr"], st["boundaries"], st["sorted_payload"], w, h)
-    finally:
-        oracle.set_contraction(True)
-
-
 def test_needle_gaussians_and_the_contraction_choice(pkg, oracle, ref):
     """Thin, long, randomly oriented splats (sigma ratio up to e^7; the GPU suite's needle scene): near-singular 2x2
     covariances and a `power` made of terms ~1e4..1e5 that cancel to a few units.
-      * every stage ahead of the blend: bit-equal to the reference text, as everywhere;
-      * the blend with the uncontracted reading of render.comp:66,87 (what the CPU-compiled text evaluates): equal to
-        the reference text up to exp()'s ULPs and the listed threshold pixels -- the transcription holds in this regime;
-      * the pipeline's definition (three FMA contractions, which GLSL permits) against the uncontracted reading: here,
-        and only in such scenes, one rounding more or less in `power` is amplified by the cancellation (alpha moves by
-        ~2^-24 x |terms|): the two conformant readings differ visibly -- measured and bounded below.  On a benign scene
-        (config A) they agree to ULP noise."""
+      * every stage ahead of the blend AND the image (default reading): bit-equal to the reference text, as everywhere;
+      * the fast reading's three FMA contractions (which GLSL permits) against the default: here, and only in such
+        scenes, one rounding more or less in `power` is amplified by the cancellation (alpha moves by ~2^-24 x |terms|):
+        the two conformant readings differ visibly -- measured and bounded below -- which is why the contraction is
+        opt-in.  On a benign scene (config A) they agree to ULP noise."""
     n, w, h = 6000, 640, 360
     rng = np.random.default_rng(31)
     rec = pkg.synth.synth_records(n, seed=31, kind="A")
@@ -158,20 +155,23 @@ def test_needle_gaussians_and_the_contraction_choice(pkg, oracle, ref):
     u = oracle.camera_uniforms(oracle.default_camera(), w, h)
     so, sr = oracle.stages(verts, u), ref.stages(verts, u)
     assert_stage_parity(so, sr)
-    img_strict = strict_image(oracle, so, w, h)
-    rest, flips = compare_images(img_strict, sr["image"], sr, w, label="needles, uncontracted")
-    d = np.abs(so["image"][..., :3].astype(np.float64) - img_strict[..., :3]).max(axis=2)
+    assert_images_identical(so["image"], sr["image"], label="needles: oracle vs reference text")
+    # uncontracted with the polynomial exp: ULP noise, no threshold pixel -- the contraction is what moves the pixels
+    with oracle.reading(False, 0):
+        img_u0 = oracle.render(so["attr"], so["boundaries"], so["sorted_payload"], w, h)
+    rest, flips = compare_images(img_u0, sr["image"], sr, w, label="needles, uncontracted + polynomial exp")
+    d = np.abs(fast_image(oracle, so, w, h)[..., :3].astype(np.float64) - so["image"][..., :3]).max(axis=2)
     frac, worst = float((d > 1e-5).mean()), float(d.max())
-    print(f"needles {w}x{h}: uncontracted oracle vs reference text: max|d| off-threshold {rest:.3g}, {len(flips)} threshold "
-          f"pixel(s); contracted vs uncontracted: {100 * frac:.2f} % of the pixels differ by > 1e-5, largest {worst:.3g}")
-    assert worst < 2e-2  # the scene is made of nothing but needles: most pixels see the amplified rounding
+    print(f"needles {w}x{h}: oracle == reference text; polynomial exp alone: max|d| off-threshold {rest:.3g}, {len(flips)} "
+          f"threshold pixel(s); contracted vs uncontracted: {100 * frac:.2f} % of the pixels differ by > 1e-5, largest {worst:.3g}")
+    assert rest <= 1e-5 and worst < 2e-2  # the scene is made of nothing but needles: most pixels see the amplified rounding
 
     # a benign scene: the two readings agree to ULP noise but for threshold pixels
     rec = pkg.synth.synth_records(10_000, seed=0, kind="A")
     verts = oracle.activate_records(rec)
     u = oracle.camera_uniforms(oracle.default_camera(), 256, 256)
     so = oracle.stages(verts, u)
-    rest, flips = compare_images(so["image"], strict_image(oracle, so, 256, 256), so, 256, label="config A, contraction")
+    rest, flips = compare_images(fast_image(oracle, so, 256, 256), so["image"], so, 256, label="config A, fast reading")
     assert rest <= 1e-5 and len(flips) <= 3
 
 
@@ -185,7 +185,7 @@ def test_binary16_rounded_sh(pkg, oracle, ref):
     u = oracle.camera_uniforms(oracle.default_camera(), 320, 200)
     so, sr = oracle.stages(verts, u), ref.stages(verts, u)
     assert_stage_parity(so, sr)
-    compare_images(so["image"], sr["image"], sr, 320, label="sh16")
+    assert_images_identical(so["image"], sr["image"], label="sh16")
 
 
 FUZZ_SEEDS = int(__import__("os").environ.get("GS_REF_FUZZ_SEEDS", 8))  # soak: GS_REF_FUZZ_SEEDS=200
@@ -195,7 +195,7 @@ FUZZ_SEEDS = int(__import__("os").environ.get("GS_REF_FUZZ_SEEDS", 8))  # soak: 
 def test_random_cases_against_the_reference_text(pkg, oracle, ref, seed):
     """The GPU suite's seeded sweep (scene size, splat size, opacity, framebuffer size, camera pose, field of view --
     tests/test_gpu_fuzz.py draws the same cases for HIP vs oracle) for oracle vs reference text: every stage bit-equal,
-    the image to exp()'s ULPs and listed threshold pixels."""
+    the image too; the fast reading to exp()'s ULPs and listed threshold pixels."""
     import test_gpu_fuzz as fuzz
     n, w, h, log_scale, q, pos, fov, opacity_shift = fuzz._case(seed)
     n = min(n, 60_000)  # the scalar reference text is the slow side
@@ -205,8 +205,8 @@ def test_random_cases_against_the_reference_text(pkg, oracle, ref, seed):
     u = oracle.camera_uniforms(oracle.default_camera(pos, q, fov), w, h)
     so, sr = oracle.stages(verts, u), ref.stages(verts, u)
     assert_stage_parity(so, sr)
-    compare_images(strict_image(oracle, so, w, h), sr["image"], sr, w, label=f"fuzz {seed}, uncontracted")
-    compare_images(so["image"], sr["image"], sr, w, label=f"fuzz {seed}")
+    assert_images_identical(so["image"], sr["image"], label=f"fuzz {seed}")
+    compare_images(fast_image(oracle, so, w, h), sr["image"], sr, w, label=f"fuzz {seed}, fast reading")
 
 
 def test_reference_text_against_the_float64_numpy_restatement(pkg, oracle, ref):
