@@ -452,7 +452,7 @@ struct FrameBuffers {
     DevBuf<uint32_t> block_hist, digit_total;
     // two-level binning
     DevBuf<uint32_t> l1_hist, bin_count;  // [padded bins][level-1 blocks], [1024]
-    DevBuf<uint32_t> cand;                // [capacity] bin-major candidate ids
+    DevBuf<uint32_t> cand;                // [3 x capacity] bin-major candidates: 12-byte records {depth bits, id, box} on the bin-local path, plain ids otherwise
     DevBuf<uint32_t> sorted;              // [capacity + 4] per-tile lists, bin-major
     DevBuf<uint32_t> ranges;              // [T][2]
     DevBuf<gs::Counters> counters;
@@ -508,11 +508,11 @@ struct FrameBuffers {
     }
     void set_capacity(uint32_t cap) {
         drop_graph();  // the captured launches hold the old buffers
-        cand.alloc(cap);
+        cand.alloc(3 * static_cast<size_t>(cap));
         // a frame whose candidates overflow the capacity leaves a gap of unwritten entries that k_bin_build still
         // gathers through before the frame is re-run: the gap must hold valid Gaussian ids (0), never whatever
         // hipMalloc handed back
-        HIP_CHECK(hipMemset(cand.p, 0, static_cast<size_t>(cap) * sizeof(uint32_t)));
+        HIP_CHECK(hipMemset(cand.p, 0, 3 * static_cast<size_t>(cap) * sizeof(uint32_t)));
         sorted.alloc(static_cast<size_t>(cap) + 4);  // + 4: a 16-byte list store that starts inside the capacity may end past it
     }
     void sync() const {

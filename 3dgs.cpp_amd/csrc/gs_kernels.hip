@@ -792,6 +792,7 @@ struct L1Args {
     uint32_t n_bound;
     const uint32_t* tiles;      // [N] tiles_overlap (0 = culled)
     const ushort4* aabb;        // [N] tile boxes
+    const float* depth;         // [N] (the record-emitting scatter only)
     uint32_t* hist;             // [bins (padded)][nblk]
     uint32_t* bin_count;        // [bins (padded)]
     uint32_t* cand;             // [capacity] bin-major candidate Gaussian ids
@@ -1022,6 +1023,18 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
 
 // Bin-local path: the order of a bin's candidates does not matter (k_bin_fast orders them by (depth bits, id), a total
 // order), so a block's items take their slots in its run of each bin's list with LDS atomics -- no ranking at all.
+// What lands in the list is a 12-byte RECORD per candidate -- {depth bits, Gaussian id, tile box clipped to the bin} --
+// everything level 2 needs, so that k_bin_fast STREAMS its bin's candidates with one coalesced read instead of gathering
+// depth[id] (a 64-byte line per 4-byte value) and, after the sort, aabb[id] again (round 2: 2.3x the algorithmic bytes).
+constexpr int kCandWords = 3;  // {key, id, box16}
+// a tile box clipped to a bin of S <= 8 tiles, bin-local, inclusive upper bounds, 4 bits each: x0 | y0 << 4 | x1 << 8 | y1 << 12
+__device__ __forceinline__ uint32_t bin_local_box16(const BinGrid& g, uint32_t bin, ushort4 box) {
+    const int S = 1 << g.bin_shift;
+    const int ox = (int)(bin & ((1u << g.grid_shift) - 1u)) << g.bin_shift, oy = (int)(bin >> g.grid_shift) << g.bin_shift;
+    const int lx0 = max((int)box.x, ox) - ox, ly0 = max((int)box.y, oy) - oy;
+    const int lx1 = min((int)box.z, ox + S) - ox - 1, ly1 = min((int)box.w, oy + S) - oy - 1;
+    return (uint32_t)lx0 | ((uint32_t)ly0 << 4) | ((uint32_t)lx1 << 8) | ((uint32_t)ly1 << 12);
+}
 template <int R1>
 __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     constexpr int NB = 64 * R1;
@@ -1049,18 +1062,41 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
             if (total > a.capacity) atomicOr(&a.counters->overflow, 1u);
         }
     }
-    uint32_t box[kL1PerWave], gid[kL1PerWave];
+    // all four items' loads first (two dependent round trips: tiles, then box + depth of the visible ones)
+    uint32_t nt[kL1PerWave], key[kL1PerWave];
+    ushort4 tb[kL1PerWave];
 #pragma unroll
-    for (int j = 0; j < kL1PerWave; ++j)  // all four items' loads first (independent round trips)
-        gid[j] = l1_item(a, blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane, a.n_bound, box[j]);
+    for (int j = 0; j < kL1PerWave; ++j) {
+        const uint32_t p = blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+        nt[j] = p < a.n_bound ? a.tiles[p] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kL1PerWave; ++j) {
+        const uint32_t p = blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+        tb[j] = make_ushort4(0, 0, 0, 0);
+        key[j] = 0;
+        if (nt[j] != 0) {
+            tb[j] = a.aabb[p];
+            key[j] = __float_as_uint(a.depth[p]);
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kL1PerWave; ++j) {
-        const uint32_t x0 = box[j] & 255u, y0 = (box[j] >> 8) & 255u, x1 = (box[j] >> 16) & 255u, y1 = box[j] >> 24;
+        if (nt[j] == 0) continue;
+        const uint32_t gid = blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+        const uint32_t x0 = tb[j].x >> a.g.bin_shift, y0 = tb[j].y >> a.g.bin_shift;
+        const uint32_t x1 = ((tb[j].z - 1u) >> a.g.bin_shift) + 1u, y1 = ((tb[j].w - 1u) >> a.g.bin_shift) + 1u;
         for (uint32_t y = y0; y < y1; ++y)
             for (uint32_t x = x0; x < x1; ++x) {
-                const uint32_t pos = atomicAdd(&s_cur[(y << a.g.grid_shift) | x], 1u);
-                if (pos < a.capacity) a.cand[pos] = gid[j];
+                const uint32_t bin = (y << a.g.grid_shift) | x;
+                const uint32_t pos = atomicAdd(&s_cur[bin], 1u);
+                if (pos < a.capacity) {
+                    uint32_t* const rec = a.cand + (size_t)kCandWords * pos;  // three adjacent dwords: one 12-byte store
+                    rec[0] = key[j];
+                    rec[1] = gid;
+                    rec[2] = bin_local_box16(a.g, bin, tb[j]);
+                }
             }
     }
 }
@@ -1078,7 +1114,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
 // ---------------------------------------------------------------------------------------
 struct BuildArgs {
     BinGrid g;
-    const uint32_t* cand;
+    uint32_t* cand;        // k_bin_build: [capacity] ids; k_bin_fast: [capacity] 12-byte records (rewritten in place in the degenerate-tie case)
     const uint32_t* bin_count;
     const float* depth;
     const ushort4* aabb;
@@ -1434,10 +1470,13 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     using L = FastLayout<ROUNDS>;
     constexpr int THREADS = L::THREADS, NW = L::NW, MAXC = L::MAXC;
     extern __shared__ uint32_t smem[];
-    uint32_t* const s_key = smem;
-    uint32_t* const s_id = smem + MAXC;
+    // while the order is being made: the sort's payload (slot in the bin's record run | box16 << 14) and the depth bits
+    uint32_t* const s_pay = smem;
+    uint32_t* const s_key = smem + MAXC;
     uint16_t (*const s_wcnt)[256] = reinterpret_cast<uint16_t(*)[256]>(smem + 2 * MAXC);
-    // once the order is final: the key area holds the 16-bit boxes and the chunk table, the counter area the tile tables
+    // once the order is final: the key area holds the ids, the payload area the 16-bit boxes and the chunk table, the
+    // counter area the tile tables
+    uint32_t* const s_id = smem + MAXC;                                                          // [MAXC]
     uint16_t* const s_box = reinterpret_cast<uint16_t*>(smem);                                   // [MAXC]
     uint16_t (*const s_tbl)[64] = reinterpret_cast<uint16_t(*)[64]>(smem + MAXC / 2);           // [MAXC / 64][64]
     uint32_t* const t_cnt = smem + 2 * MAXC;                                                     // [64]
@@ -1445,6 +1484,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     uint32_t (*const s_seg)[64] = reinterpret_cast<uint32_t(*)[64]>(t_cnt + 128);                // [16][64]
     __shared__ uint32_t scratch[NW];
     __shared__ uint32_t s_seg0, s_flag;
+    constexpr uint32_t kSlotMask = 0x3FFFu;  // MAXC <= 16384
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     // one workgroup per ON-SCREEN bin (the grid is bins_x * bins_y: with the padding of the bin grid in it, workgroups
@@ -1469,51 +1509,32 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     if (tid == 0) s_flag = 0;
     BUILD_T(1);
     const int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= ROUNDS
-    {   // ids, then their depths: all of a thread's loads of one kind are in flight together
-        uint32_t g[ROUNDS], k[ROUNDS];
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const uint32_t e = r * THREADS + tid;
-            g[r] = e < c ? a.cand[off + e] : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const uint32_t e = r * THREADS + tid;
-            k[r] = e < c ? __float_as_uint(a.depth[g[r]]) : 0u;  // the dense array: gathering it from the records measured slower
-        }
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const uint32_t e = r * THREADS + tid;
-            if (e < c) {
-                s_id[e] = g[r];
-                s_key[e] = k[r];
-            }
-        }
-    }
-    BUILD_T(2);
+    // this bin's run of 12-byte records {key, id, box16} as a raw buffer: 32-bit offsets (one address register per load instead
+    // of two) and the hardware's bounds check in place of branches (reads past the run return 0)
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    const __amdgpu_buffer_rsrc_t recs = __builtin_amdgcn_make_buffer_rsrc(a.cand + (size_t)kCandWords * off, 0, c * 12u, 0x27000);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    // One stable 8-bit LSD pass in place.  code 0..3: byte `code` of the depth bits; 4..7: byte `code - 4` of the id.
     // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
     const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
-    auto radix_pass = [&](int code) {
-        const int shift = (code & 3) * 8;
-        const bool by_id = code >= 4;
+    // One stable 8-bit LSD pass over (s_key, s_pay) in place, digit = byte `pass` of s_key.
+    auto radix_pass = [&](int pass) {
+        const int shift = pass * 8;
         for (int k = tid; k < NW * 256 / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0;
         __syncthreads();  // also orders the previous pass's (or the load's) LDS writes before this pass's reads
-        uint32_t key[ROUNDS], id[ROUNDS], rank[ROUNDS];
+        uint32_t key[ROUNDS], pay[ROUNDS], rank[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             key[r] = 0;
-            id[r] = 0;
+            pay[r] = 0;
             rank[r] = 0;
             if (r < rounds) {
                 const uint32_t e = wbase + r * WAVE + lane;
                 const bool ok = e < c;
                 if (ok) {
                     key[r] = s_key[e];
-                    id[r] = s_id[e];
+                    pay[r] = s_pay[e];
                 }
-                const uint32_t d = ((by_id ? id[r] : key[r]) >> shift) & 255u;
+                const uint32_t d = (key[r] >> shift) & 255u;
                 // lanes holding a valid element with my digit: AND over the bits of (ballot(bit) XNOR my bit)
                 const uint64_t okm = __ballot(ok);
                 uint32_t mlo = (uint32_t)okm, mhi = (uint32_t)(okm >> 32);
@@ -1562,70 +1583,141 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             if (r < rounds) {
                 const uint32_t e = wbase + r * WAVE + lane;
                 if (e < c) {
-                    const uint32_t d = ((by_id ? id[r] : key[r]) >> shift) & 255u;
+                    const uint32_t d = (key[r] >> shift) & 255u;
                     const uint32_t pos = (uint32_t)s_wcnt[w][d] + rank[r];
                     s_key[pos] = key[r];
-                    s_id[pos] = id[r];
+                    s_pay[pos] = pay[r];
                 }
             }
         }
         __syncthreads();
     };
-    if (c != 0) {
+    // attempt 0: the records as level 1 left them (any order inside a block's run).  attempt 1 (only after a run of more
+    // than 64 equal depths, i.e. a degenerate scene): the records rewritten in id order, so that the stable passes alone
+    // leave equal depths in id order
+    for (int attempt = 0; c != 0 && attempt < 2; ++attempt) {
+        {   // ---- the bin's records, streamed: a thread's loads are all in flight together
+            uint32_t k[ROUNDS], b[ROUNDS];
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const uint32_t e = r * THREADS + tid;
+                k[r] = 0;
+                b[r] = 0;
+                if (r < rounds) {
+                    const u32x3 rec = __builtin_amdgcn_raw_buffer_load_b96(recs, e * 12u, 0, 0);
+                    k[r] = rec.x;
+                    b[r] = rec.z;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const uint32_t e = r * THREADS + tid;
+                if (r < rounds && e < c) {
+                    s_key[e] = k[r];
+                    s_pay[e] = e | (b[r] << 14);
+                }
+            }
+        }
+        if (attempt == 0) BUILD_T(2);
 #pragma unroll 1
         for (int pass = 0; pass < 4; ++pass) radix_pass(pass);
-        // ---- ties by id.  Runs of equal keys are adjacent; look at most 64 to either side.
-        uint32_t mv_pos[ROUNDS], mv_id[ROUNDS];
+        // ---- ties.  Candidates of equal depth must follow each other by Gaussian id (what the reference's stable sort of
+        // (tile, depth) keys over index-ordered input gives).  Equal keys are adjacent now.  The element that STARTS a run of
+        // equal keys measures the run (at most 64 more); all elements fetch their ids (a gather inside the bin's own record
+        // run, which this workgroup has just streamed) and the ids replace the keys; then each run's first element alone
+        // puts its run into id order, in place (an insertion sort over (id, payload): runs are two or three long unless the
+        // scene is degenerate, and no two runs share a position, so there is nothing to synchronise).
+        uint32_t my_id[ROUNDS], run_len[(ROUNDS + 3) / 4];  // run lengths - 1, eight bits each
         bool too_long = false;
 #pragma unroll
+        for (int q = 0; q < (ROUNDS + 3) / 4; ++q) run_len[q] = 0;
+#pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            mv_pos[r] = 0xFFFFFFFFu;
-            mv_id[r] = 0;
             const uint32_t e = r * THREADS + tid;
+            my_id[r] = 0;
             if (r < rounds && e < c) {
+                my_id[r] = __builtin_amdgcn_raw_buffer_load_b32(recs, (s_pay[e] & kSlotMask) * 12u + 4u, 0, 0);
                 const uint32_t k = s_key[e];
-                const bool tie_lo = e > 0 && s_key[e - 1] == k, tie_hi = e + 1 < c && s_key[e + 1] == k;
-                if (tie_lo || tie_hi) {
-                    uint32_t lo = e, hi = e;
-                    while (lo > 0 && e - lo < 64 && s_key[lo - 1] == k) --lo;
-                    while (hi + 1 < c && hi - e < 64 && s_key[hi + 1] == k) ++hi;
-                    if ((lo > 0 && s_key[lo - 1] == k) || (hi + 1 < c && s_key[hi + 1] == k)) too_long = true;
-                    const uint32_t me = s_id[e];
-                    uint32_t smaller = 0;
-                    for (uint32_t j = lo; j <= hi; ++j) smaller += s_id[j] < me ? 1u : 0u;
-                    mv_pos[r] = lo + smaller;
-                    mv_id[r] = me;
+                if (attempt == 0 && (e == 0 || s_key[e - 1] != k) && e + 1 < c && s_key[e + 1] == k) {
+                    uint32_t more = 1;
+                    while (e + more + 1 < c && more < 64 && s_key[e + more + 1] == k) ++more;
+                    if (e + more + 1 < c && s_key[e + more + 1] == k) too_long = true;
+                    run_len[r / 4] |= more << (8 * (r % 4));
                 }
             }
         }
         if (too_long) s_flag = 1;
-        __syncthreads();  // every read of the old order is done
+        __syncthreads();  // every read of the keys is done: the ids take their place
         const bool redo = s_flag != 0;
-        if (!redo) {
 #pragma unroll
-            for (int r = 0; r < ROUNDS; ++r)
-                if (mv_pos[r] != 0xFFFFFFFFu) s_id[mv_pos[r]] = mv_id[r];
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            if (r < rounds && e < c) s_id[e] = my_id[r];
         }
         __syncthreads();
-        if (redo) {  // a long run of equal depths: order by id first (four bytes cover any id), then by depth again
-#pragma unroll 1
-            for (int pass = 4; pass < 8; ++pass) radix_pass(pass);
-#pragma unroll 1
-            for (int pass = 0; pass < 4; ++pass) radix_pass(pass);
+        if (!redo) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const uint32_t more = (run_len[r / 4] >> (8 * (r % 4))) & 255u;
+                if (more != 0) {
+                    const uint32_t e = r * THREADS + tid;
+                    for (uint32_t i = e + 1; i <= e + more; ++i) {  // insertion sort of [e, e + more] by id
+                        const uint32_t vi = s_id[i], vp = s_pay[i];
+                        uint32_t j = i;
+                        while (j > e && s_id[j - 1] > vi) {
+                            s_id[j] = s_id[j - 1];
+                            s_pay[j] = s_pay[j - 1];
+                            --j;
+                        }
+                        s_id[j] = vi;
+                        s_pay[j] = vp;
+                    }
+                }
+            }
+            __syncthreads();
+            break;
         }
+        // ---- a long run of equal depths: order the bin by id (the ids sit in the key area: four more passes), rewrite its
+        // records in that order and start over; the second attempt needs no tie handling
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) radix_pass(pass);
+        uint32_t nk[ROUNDS], ni[ROUNDS], nb[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            nk[r] = ni[r] = nb[r] = 0;
+            if (r < rounds && e < c) {
+                const uint32_t pw = s_pay[e];
+                nk[r] = __builtin_amdgcn_raw_buffer_load_b32(recs, (pw & kSlotMask) * 12u, 0, 0);
+                ni[r] = s_id[e];
+                nb[r] = pw >> 14;
+            }
+        }
+        __syncthreads();  // (workgroup-scope fence included) every record has been read before any is overwritten
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            if (r < rounds && e < c) {
+                u32x3 rec = {nk[r], ni[r], nb[r]};
+                __builtin_amdgcn_raw_buffer_store_b96(rec, recs, e * 12u, 0, 0);
+            }
+        }
+        __threadfence_block();
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
     }
     BUILD_T(3);
-    // ---- the candidates' tile boxes inside the bin, and the (chunk, tile) counts
+    // ---- the candidates' tile boxes inside the bin (they rode along in the payload), and the (chunk, tile) counts
     const uint32_t nch = (c + WAVE - 1) / WAVE;
     const int S = 1 << a.g.bin_shift;
     {
-        ushort4 box[ROUNDS];
+        uint32_t pb16[ROUNDS];
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {  // all gathers in flight together
+        for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t e = r * THREADS + tid;
-            box[r] = e < c ? a.aabb[s_id[e]] : make_ushort4(0, 0, 0, 0);
+            pb16[r] = e < c ? s_pay[e] >> 14 : 0u;
         }
-        __syncthreads();  // the keys are dead from here on: their area becomes boxes + chunk table
+        __syncthreads();  // the payloads are dead from here on: their area becomes boxes + chunk table
         for (uint32_t k = tid; k < (uint32_t)MAXC / 2; k += THREADS) smem[MAXC / 2 + k] = 0;  // the table
         if (tid < 64) t_cnt[tid] = 0;
         __syncthreads();
@@ -1634,13 +1726,13 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t e = r * THREADS + tid;
             if (e < c) {
-                const uint32_t pb = bin_local_box(a.g, bin, box[r]);
-                const uint32_t lx0 = pb & 255u, ly0 = (pb >> 8) & 255u, lx1 = (pb >> 16) & 255u, ly1 = pb >> 24;
-                s_box[e] = (uint16_t)(lx0 | (ly0 << 4) | ((lx1 - 1u) << 8) | ((ly1 - 1u) << 12));  // inclusive upper bounds
+                const uint32_t pb = pb16[r];
+                s_box[e] = (uint16_t)pb;  // x0 | y0 << 4 | x1 << 8 | y1 << 12, inclusive upper bounds
                 if (S == 4) {  // 16 tiles: a handful of LDS atomics per candidate (16-bit counters, two to a word; <= 64 each)
+                    const uint32_t lx0 = pb & 15u, ly0 = (pb >> 4) & 15u, lx1 = (pb >> 8) & 15u, ly1 = pb >> 12;
                     const uint32_t row = (e >> 6) * 64u;
-                    for (uint32_t y = ly0; y < ly1; ++y)
-                        for (uint32_t x = lx0; x < lx1; ++x) {
+                    for (uint32_t y = ly0; y <= ly1; ++y)
+                        for (uint32_t x = lx0; x <= lx1; ++x) {
                             const uint32_t idx = row + (y << 2) + x;
                             atomicAdd(&tbl_words[idx >> 1], 1u << (16u * (idx & 1u)));
                         }
@@ -1771,6 +1863,7 @@ static L1Args l1_args(const BinLaunch& b) {
     a.n_bound = b.n_bound;
     a.tiles = b.tiles;
     a.aabb = b.aabb;
+    a.depth = b.depth;
     a.hist = b.hist;
     a.bin_count = b.bin_count;
     a.cand = b.cand;
@@ -1922,7 +2015,7 @@ __device__ __forceinline__ float min_q_rect(float c00, float c01, float c11, flo
 
 #ifdef GS_BLEND_STATS
 // debug instrumentation (separate build, never the shipped library)
-__device__ unsigned long long g_blend_stats[8];
+__device__ unsigned long long g_blend_stats[12];
 #define STAT_ADD(i, v) do { const unsigned long long v_ = (unsigned long long)(v); const bool first_ = (__ffsll((unsigned long long)__ballot(true)) - 1) == lane; if (first_) atomicAdd(&g_blend_stats[i], v_); } while (0)
 #else
 #define STAT_ADD(i, v) do { } while (0)
@@ -1971,7 +2064,9 @@ __device__ __forceinline__ float gs_expf_libm(float x, const uint2* __restrict__
     uint2 t = tab[ki & 31u];
     t.y += ki << 15;                                        // t += ki << 47: the exponent of 2^(k/32)
     const double sc = __longlong_as_double((long long)(((uint64_t)t.y << 32) | t.x));
-    const double z = __builtin_fma(C0, r, C1);
+    // z = fma(C0, r, C1) as one VOP3 v_fma_f64 (left to itself the compiler copies C1 and uses the two-address v_fmac_f64)
+    double z;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(z) : "s"(C0), "v"(r), "v"(C1));
     const double r2 = r * r;
     double y = __builtin_fma(C2, r, 1.0);
     y = __builtin_fma(z, r2, y);
@@ -2134,6 +2229,9 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                     const uint64_t m2 = m1 & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
                     const float test_T = T * (1 - alpha);
                     const uint64_t mk = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);  // :82-85 break
+                    STAT_ADD(8, __popcll(m2 & ~mk));   // (pixel, entry) pairs that contribute (alpha >= 1/255, before the break)
+                    // the reference's loop walks a pixel's list up to and including the entry it breaks at (render.comp:60-85)
+                    STAT_ADD(7, (unsigned long long)__popcll(mk) * ((base - range.x) + (uint32_t)k + 1u));
                     const bool upd = __builtin_amdgcn_inverse_ballot_w64(m2 & ~mk);
                     if (upd) {  // the accumulate runs under the exec mask: no selects
                         if (CONTRACT) {
@@ -2161,6 +2259,7 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
             if (alive == 0) break;
         }
     }
+    STAT_ADD(7, (unsigned long long)__popcll(alive) * (range.y - range.x));  // pixels that never broke walk the whole list
     if (inside) {
         const size_t p = (size_t)py * width + px;
         if (rgba) rgba[p] = make_float4(c0, c1, c2, 1.0f);  // :98
@@ -2205,7 +2304,7 @@ void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint
 
 #ifdef GS_BLEND_STATS
 extern "C" int gs_debug_blend_stats(unsigned long long* out, int reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_stats), sizeof z) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, sizeof z) != hipSuccess) return -1;
     return 0;

@@ -40,9 +40,48 @@ def scene_params(kind, n):
     """Distribution parameters for the named configs of BASELINE.md §2."""
     if kind == "A":  # 10 k / 256x256 plumbing config
         return dict(x=(-1.0, 1.0), y=(-1.0, 1.0), z=(-6.0, -2.0), log_scale_mean=-3.0)
+    if kind == "T":  # trained-scene statistics (see synth_records): the mean is calibrated so that D stays near S(n)'s
+        return dict(x=(-4.5, 4.5), y=(-2.6, 2.6), z=(-12.0, -2.0),
+                    log_scale_mean=-5.35 - np.log(n / 1.0e6) / 3.0)
     # S(N): density-compensated splat size (SURVEY.md §8d)
     return dict(x=(-4.5, 4.5), y=(-2.6, 2.6), z=(-12.0, -2.0),
                 log_scale_mean=-4.5 - np.log(n / 1.0e6) / 3.0)
+
+
+# Scene kind "T": what a TRAINED scene looks like to the rasteriser, since no trained PLY ships with the reference or this
+# container (BASELINE configs[2], the Mip-NeRF360 garden, is 6 M such Gaussians; GSScene.cpp:26-68 loads such files).
+# Against S(N) (isotropic-ish splats, log-scale sigma 0.6, uniform positions, logit N(0, 2)):
+#   * per-axis log-scales N(mu, 1.3) drawn independently, clipped at mu + 3.6, and 2 % of the Gaussians get one axis
+#     stretched by e^2 more: needles and discs with axis ratios up to ~e^7 -- the regime in which `power` is a difference of
+#     large cancelling terms and the contracted / uncontracted readings of render.comp:66 part ways;
+#   * positions clustered: 80 % in 96 Gaussian blobs (sigma 0.15 .. 0.9, centres uniform in S's box), 20 % uniform background
+#     -- per-tile list lengths vary by two orders of magnitude instead of S's near-uniform load;
+#   * opacity bimodal: 55 % nearly transparent (logit N(-2.5, 1)), 45 % nearly opaque (logit N(3, 1.5));
+#   * view-dependent colour a little stronger (f_rest N(0, 0.15)).
+_T_CLUSTERS = 96
+
+
+def _trained_like(rec, n, seed, idx, p):
+    lerp = lambda lohi, u: lohi[0] + (lohi[1] - lohi[0]) * u  # noqa: E731
+    cid = (np.floor(_uniform(seed, idx, 70) * _T_CLUSTERS)).astype(np.uint64)
+    background = _uniform(seed, idx, 71) < 0.20
+    cseed = np.uint32(seed) + np.uint32(7919)
+    sig = 0.15 + 0.75 * _uniform(cseed, cid, 3) ** 2
+    gx, gy = _normal_pair(seed, idx, 72)
+    gz, _ = _normal_pair(seed, idx, 74)
+    for k, (lohi, g) in enumerate(((p["x"], gx), (p["y"], gy), (p["z"], gz))):
+        c = lerp(lohi, _uniform(cseed, cid, k))
+        v = np.where(background, lerp(lohi, _uniform(seed, idx, k)), c + sig * g * (1.0 if k < 2 else 1.6))
+        rec[:, k] = np.clip(v, lohi[0] - 1.0, -0.5 if k == 2 else lohi[1] + 1.0)
+    s0, s1 = _normal_pair(seed, idx, 3)
+    s2, _ = _normal_pair(seed, idx, 5)
+    stretch_axis = (np.floor(_uniform(seed, idx, 76) * 3)).astype(np.int64)
+    stretched = _uniform(seed, idx, 77) < 0.02
+    for k, sn in enumerate((s0, s1, s2)):
+        ls = p["log_scale_mean"] + np.minimum(1.3 * sn, 3.6)
+        rec[:, 55 + k] = ls + np.where(stretched & (stretch_axis == k), 2.0, 0.0)
+    o, o2 = _normal_pair(seed, idx, 11)
+    rec[:, 54] = np.where(_uniform(seed, idx, 78) < 0.55, -2.5 + o, 3.0 + 1.5 * o2)
 
 
 def synth_records(n, seed=0, kind="S", start=0, **override):
@@ -72,11 +111,14 @@ def synth_records(n, seed=0, kind="S", start=0, **override):
     rec[:, 54] = 2.0 * o
     for k in range(3):
         rec[:, 6 + k] = -1.5 + 3.0 * _uniform(seed, idx, 13 + k)
+    rest = 0.15 if kind == "T" else 0.1
     for k in range(0, 46, 2):
         a, b = _normal_pair(seed, idx, 16 + k)
-        rec[:, 9 + k] = 0.1 * a
+        rec[:, 9 + k] = rest * a
         if k + 1 < 45:
-            rec[:, 9 + k + 1] = 0.1 * b
+            rec[:, 9 + k + 1] = rest * b
+    if kind == "T":
+        _trained_like(rec, n, seed, idx, p)
     return rec
 
 

@@ -74,28 +74,35 @@ def test_workload_names_follow_the_arguments():
     assert "configs[4]" in m.workload_name(6_000_000, 3840, 2160, 1)
     assert "configs[2]" in m.workload_name(6_000_000, 1920, 1080, 1) and "stand-in" in m.workload_name(6_000_000, 1920, 1080, 1)
     assert "not a BASELINE config" in m.workload_name(123, 640, 480, 1)
+    t = m.workload_name(6_000_000, 1920, 1080, 1, "T")
+    assert "configs[2]" in t and "trained-scene statistics" in t and t.startswith("T(6000000)")
 
 
 def test_roofline_block_without_counters_is_the_hbm_view(pkg):
-    """Counters of other kernel sources must not be quoted: the block falls back to the live HBM view."""
+    """Counters of other kernel sources or other workloads must not be quoted: the block falls back to the live HBM view,
+    computed on the frame time (spans of frames in flight are not additive)."""
     m = _bench_module()
-    r = m.roofline(pkg, "render", 12345, 640, 480, 228_920_200, 0.25, 0.21)   # no counter file for this workload
+    r = m.roofline(pkg, "render", m.workload_key(12345, 640, 480, "S"), (2, False), 228_920_200, 0.25, 0.21, 0.30)
     assert r["bound"] == "hbm" and r["traffic"] is None and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["achieved"] - 228_920_200 / 1e9 / 0.25e-3) < 1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
-    assert r["one_in_flight"]["ms"] == 0.21
+    assert abs(r["achieved"] - 228_920_200 / 1e9 / 0.30e-3) < 1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    assert r["one_in_flight"]["ms"] == 0.21 and r["ms_per_frame"] == 0.30 and r["flops_view"] is None
 
 
 def test_committed_counters_belong_to_the_library_as_built(pkg):
     """The newest committed counter run must have been collected from the kernel sources this library is built from
     (bench.py refuses anything else and falls back to the HBM view): a kernel edited after the last profile shows here,
-    on the CPU, before the driver's bench line would."""
+    on the CPU, before the driver's bench line would.  And the headline frac must follow from profiles/ by division."""
     m = _bench_module()
-    c, why = m.committed_counters(pkg, "render", 1_000_000, 1920, 1080)
+    wkey = m.workload_key(1_000_000, 1920, 1080, "S")
+    c, why = m.committed_counters(pkg, "render", wkey, (2, False))
     if c is None:  # a kernel was edited since the last counter run: bench.py will print the HBM view until it is redone
         import pytest
         pytest.skip(f"stale counters -- re-run tools/profile_lite.sh: {why}")
-    assert c["valu_wave_insts"] > 1e8 and c["traffic"] > 5e7 and c["file"].startswith("profiles/r")
-    r = m.roofline(pkg, "render", 1_000_000, 1920, 1080, 228_920_200, 0.30, 0.19, ms_per_frame=0.245)
+    assert c["valu_wave_insts"] > 1e8 and c["traffic"] > 5e7 and c["file"].startswith("profiles/r") and c["kernel"] == "k_blend<2, false>"
+    r = m.roofline(pkg, "render", wkey, (2, False), 228_920_200, 0.40, 0.24, 0.30)
     assert r["bound"] == "valu" and r["peak"] == 1228.8 and r["counters"] == c["file"]
-    assert abs(r["one_in_flight"]["frac"] - c["valu_wave_insts"] / 0.19e-3 / m.VALU_PEAK) < 1e-3
-    assert abs(r["per_frame_time"]["frac"] - c["valu_wave_insts"] / 0.245e-3 / m.VALU_PEAK) < 1e-3
+    assert abs(r["frac"] - c["valu_wave_insts"] / 0.30e-3 / m.VALU_PEAK) < 1e-3          # per frame time: the headline
+    assert abs(r["one_in_flight"]["frac"] - c["valu_wave_insts"] / 0.24e-3 / m.VALU_PEAK) < 1e-3
+    work = m.committed_blend_work(wkey)
+    if work:
+        assert abs(r["flops_view"]["frac"] - 22 * work["walked_pairs"] / 0.30e-3 / 157.3e12) < 1e-3

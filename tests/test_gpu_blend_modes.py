@@ -36,10 +36,12 @@ def _cases(pkg):
     q /= np.linalg.norm(q)
     return [("config A", pkg.synth.synth_records(10000, seed=0, kind="A"), 256, 256, None),
             ("needles", needle_records(pkg), 640, 360, None),
-            ("rotated", pkg.synth.synth_records(8000, seed=8000, kind="A"), 640, 360, dict(position=(0.3, -0.2, 0.5), rotation=tuple(q)))]
+            ("rotated", pkg.synth.synth_records(8000, seed=8000, kind="A"), 640, 360, dict(position=(0.3, -0.2, 0.5), rotation=tuple(q))),
+            # trained-scene statistics (synth.py kind T) at a size the scalar reference text renders in seconds
+            ("trained-like", pkg.synth.synth_records(60000, seed=5, kind="T"), 960, 540, None)]
 
 
-@pytest.mark.parametrize("case", [0, 1, 2], ids=["configA", "needles", "rotated"])
+@pytest.mark.parametrize("case", [0, 1, 2, 3], ids=["configA", "needles", "rotated", "trained-like"])
 def test_blend_modes_against_the_reference_text(pkg, oracle, gpu, case):
     import __graft_entry__ as entry
     gsref = entry.load_ref()
@@ -71,7 +73,7 @@ def test_blend_modes_against_the_reference_text(pkg, oracle, gpu, case):
             assert_images_identical(im, want, label=f"{name}: exp {exp_mode}, contraction {contract} vs the oracle's same reading")
         d = np.abs(im[..., :3].astype(np.float64) - sr["image"][..., :3]).max(axis=2)
         report[(exp_mode, contract)] = (float(d.max()), int((d > 1e-4).sum()), int((d > 1e-5).sum()))
-        if name != "needles" or not contract:
+        if name not in ("needles", "trained-like") or not contract:
             # benign scenes, or no contraction: ULP noise + listed, explained threshold pixels
             rest, flips = compare_images(im, sr["image"], sr, w, label=f"{name}: exp {exp_mode}, contraction {contract}")
             assert rest <= 1e-5

@@ -78,11 +78,12 @@ def _ref_lib():
 
 
 @pytest.mark.parametrize("name,n,w,h", [("B", 1_000_000, 1920, 1080), ("C-standin", 6_000_000, 1920, 1080),
-                                        ("E", 6_000_000, 3840, 2160)])
+                                        ("C-trained-like", 6_000_000, 1920, 1080), ("E", 6_000_000, 3840, 2160)])
 def test_full_size_config(pkg, oracle, gpu, name, n, w, h):
-    """configs[1], the S(6e6) stand-in for configs[2] (garden PLY: no file ships with the reference or this
-    container) and configs[4], each at its full size against the oracle."""
-    rec = pkg.synth.synth_records(n, seed=0, kind="S")
+    """configs[1], the two stand-ins for configs[2] (garden PLY: no file ships with the reference or this container;
+    SURVEY 8d) -- S(6e6), and T(6e6), the scene with trained-scene statistics (needles and discs, clustered positions,
+    bimodal opacity: synth.py) -- and configs[4], each at its full size against the oracle and against render.comp."""
+    rec = pkg.synth.synth_records(n, seed=0, kind="T" if name == "C-trained-like" else "S")
     scene = pkg.Scene.from_records(rec, device=0)
     rend = pkg.Renderer(scene)
     u = pkg.camera_uniforms(pkg.make_camera(), w, h)

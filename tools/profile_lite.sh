@@ -1,25 +1,42 @@
 #!/bin/bash
-# The rocprofv3 evidence of a round in about a minute of GPU time (tools/profile_round.sh is the long form: it also runs
-# bench.py for configs C / E).  The profiled process is tools/tune_sweep.py -- the same C-ABI calls as bench.py's timed
-# region, without the torch import.  Kernel-trace/stats runs and the PMC runs are separate commands (counters never share a
-# run with a trace domain other than the kernel trace; FETCH_SIZE and WRITE_SIZE each get their own pass).
-#   gpurun --timeout 200 -- 'bash tools/profile_lite.sh r02b'   then here:   python tools/profile_summary.py r02b
+# The rocprofv3 evidence of a round: kernel stats (one frame at a time, and three in flight) and the PMC counters
+# (SQ_*, FETCH_SIZE, WRITE_SIZE: three separate passes; counters never share a run with a trace domain other than the
+# kernel trace) for each of the benched workloads.  The profiled process is tools/tune_sweep.py -- the same C-ABI calls as
+# bench.py's timed region, without the torch import.
+#   gpurun --timeout 600 -- 'bash tools/profile_lite.sh r03 B C T E'   then here:   python tools/profile_summary.py r03
 set -u
 exec < /dev/null
-TAG=${1:-r02b}
+TAG=${1:-r03}
+shift
+WL=${@:-B}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
-mkdir -p "$OUT"/{default,serial,pmc,fetch,write}
+mkdir -p "$OUT"
 python -c "import __graft_entry__ as e; print(e.load_package().binding.library_source_hash())" > "$OUT/source_hash.txt"
 cd /tmp && export TMPDIR=/tmp
-D="python $R/tools/tune_sweep.py --no-prime --batches 1"
 PMC="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"
-timeout 60 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/serial" -o s -- $D --fif 1 --frames 300 --json-out "$OUT/serial/bench.json" > /dev/null 2>&1
-timeout 60 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/default" -o d -- $D --fif 3 --frames 300 --json-out "$OUT/default/bench.json" > /dev/null 2>&1
-timeout 60 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pmc" -o p -- $D --fif 1 --frames 3 --warm 1 > /dev/null 2>&1
-timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- $D --fif 1 --frames 3 --warm 1 > /dev/null 2>&1
-timeout 60 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- $D --fif 1 --frames 3 --warm 1 > /dev/null 2>&1
-rm -f "$OUT"/*/*_kernel_trace.csv
+for W in $WL; do
+  case $W in
+    B) ARGS="--gaussians 1000000 --width 1920 --height 1080 --scene S"; FR=300;;
+    C) ARGS="--gaussians 6000000 --width 1920 --height 1080 --scene S"; FR=100;;
+    T) ARGS="--gaussians 6000000 --width 1920 --height 1080 --scene T"; FR=100;;
+    E) ARGS="--gaussians 6000000 --width 3840 --height 2160 --scene S"; FR=60;;
+    *) echo "unknown workload $W"; continue;;
+  esac
+  D="python $R/tools/tune_sweep.py --no-prime --batches 1 $ARGS"
+  O=$OUT/$W
+  mkdir -p "$O"/{default,serial,pmc,fetch,write}
+  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/serial" -o s -- $D --fif 1 --frames $FR --json-out "$O/serial/bench.json" > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/default" -o d -- $D --fif 3 --frames $FR --json-out "$O/default/bench.json" > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc" -o p -- $D --fif 1 --frames 3 --warm 2 > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -o f -- $D --fif 1 --frames 3 --warm 2 > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write" -o w -- $D --fif 1 --frames 3 --warm 2 > /dev/null 2>&1
+  if [ "$W" = "B" ]; then  # the opt-in fast blend's counters as well (the A/B the default is priced against)
+    mkdir -p "$O"/pmc_fast
+    timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc_fast" -o p -- $D --fif 1 --frames 3 --warm 2 --exp-mode 0 --contract 1 > /dev/null 2>&1
+  fi
+done
+# per-dispatch traces are large; the stats and counter CSVs are what is summarised
+find "$R/gpurun_out/prof_$TAG" -name '*_kernel_trace.csv' -delete
 cd "$R"
-timeout 60 python tools/tune_sweep.py --fif 1,3 --json-out "$OUT/sweep_default.json" | tail -3
-ls -R "$OUT" | head -30
+ls -R "$OUT" | head -60

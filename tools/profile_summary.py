@@ -1,6 +1,6 @@
-"""Turn the rocprofv3 CSVs collected by tools/profile_round.sh into the summaries committed under profiles/.
+"""Turn the rocprofv3 CSVs collected by tools/profile_lite.sh into the summaries committed under profiles/.
 
-    python tools/profile_summary.py rNN        (reads gpurun_out/prof_rNN, writes profiles/rNN_*)
+    python tools/profile_summary.py rNN        (reads gpurun_out/prof_rNN/<workload>/..., writes profiles/rNN_*)
 """
 import collections
 import csv
@@ -11,14 +11,16 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
+NAMES = {"B": "config B (S(1e6), 1920x1080)", "C": "config C stand-in (S(6e6), 1920x1080)",
+         "T": "config C stand-in with trained-scene statistics (T(6e6), 1920x1080)", "E": "config E (S(6e6), 3840x2160)"}
 
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    return name.split("(")[0]
+    return name.split("(")[0].replace("gs::", "")
 
 
 def bench_line(path):
@@ -30,22 +32,18 @@ def bench_line(path):
         return None
 
 
-def kernel_stats(sub, out_name, header):
-    files = glob.glob(os.path.join(src, sub, "*_kernel_stats.csv"))
+def kernel_stats(wl, sub, out_name, header):
+    files = glob.glob(os.path.join(src, wl, sub, "*_kernel_stats.csv"))
     if not files:
-        print("missing", sub)
+        print("missing", wl, sub)
         return
     rows = list(csv.DictReader(open(files[0])))
-    b = bench_line(os.path.join(src, sub, "bench.json"))
+    b = bench_line(os.path.join(src, wl, sub, "bench.json"))
     with open(os.path.join(dst, out_name), "w") as f:
         f.write("# " + header + "\n")
-        if b and b.get("driver"):  # tools/profile_lite.sh: the profiled process is tools/tune_sweep.py
-            f.write("# %s under the profiler: %s frames/s, %d frame(s) in flight; HIP-event spans (us) %s\n"
-                    % (b["driver"], b["value"], b["frames_in_flight"], json.dumps(b["spans_us"])))
-        elif b:
-            f.write("# bench line under the profiler: value=%s frames/s ms_per_step=%s; k_blend HIP-event span in the "
-                    "timed region %.4f ms (one frame at a time: %.4f ms)\n"
-                    % (b["value"], b["ms_per_step"], b["passes"]["render"]["ms"], b["passes_serial_ms"]["render"]))
+        if b:
+            f.write("# %s under the profiler: %s frames/s, %d frame(s) in flight; HIP-event spans (us) %s; config %s\n"
+                    % (b["driver"], b["value"], b["frames_in_flight"], json.dumps(b["spans_us"]), json.dumps(b["config"])))
         f.write("%-34s %9s %14s %11s %8s %10s %10s\n" % ("kernel", "calls", "total_us", "avg_us", "pct", "min_us", "max_us"))
         for r in rows:
             f.write("%-34s %9d %14.1f %11.2f %8.2f %10.2f %10.2f\n"
@@ -54,21 +52,20 @@ def kernel_stats(sub, out_name, header):
     print("wrote", out_name)
 
 
-def counters(sub):
-    files = glob.glob(os.path.join(src, sub, "*_counter_collection.csv"))
+def counters(wl, sub):
+    files = glob.glob(os.path.join(src, wl, sub, "*_counter_collection.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if not files:
-        print("missing", sub)
+        print("missing", wl, sub)
         return agg
     for r in csv.DictReader(open(files[0])):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
 
-def mean(v):
-    """Per-dispatch figure of a kernel: the MEDIAN over its dispatches.  (A renderer's first frame runs at the smallest
-    sort level, overflows it and is re-run: that frame's blend walks near-empty lists, and in a short counter run it
-    would pull a mean down by a fifth.)"""
+def med(v):
+    """Per-dispatch figure of a kernel: the MEDIAN over its dispatches (a renderer's first frame runs at the smallest
+    sort level, overflows it and is re-run: that frame's blend walks near-empty lists)."""
     if not v:
         return float("nan")
     w = sorted(v)
@@ -77,80 +74,66 @@ def mean(v):
 
 
 os.makedirs(dst, exist_ok=True)
-lite = (bench_line(os.path.join(src, "serial", "bench.json")) or {}).get("driver") is not None
-if lite:
-    CMD = "python tools/tune_sweep.py --no-prime --batches 1 --frames 300"
-    PMC_CMD = "python tools/tune_sweep.py --no-prime --batches 1 --fif 1 --frames 3 --warm 1"
-    kernel_stats("default", tag + "_kernel_stats_default.txt",
-                 "rocprofv3 --kernel-trace --stats --output-format csv -- " + CMD + " --fif 3   (MI355X, config B, 3 frames in "
-                 "flight like the default bench command -- the same C-ABI calls as bench.py's timed region, no torch; durations "
-                 "include contention from the other frames in flight)")
-    kernel_stats("serial", tag + "_kernel_stats_serial.txt",
-                 "rocprofv3 --kernel-trace --stats --output-format csv -- " + CMD + " --fif 1   (MI355X, config B, one frame at a "
-                 "time: clean per-kernel durations)")
-else:
-    PMC_CMD = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1"
-    kernel_stats("default", tag + "_kernel_stats_default.txt",
-                 "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
-                 "   (MI355X, config B, 3 frames in flight = the default bench command; durations include contention from the"
-                 " other frames in flight; the 100 one-in-flight diagnostic launches are pooled in)")
-    kernel_stats("serial", tag + "_kernel_stats_serial.txt",
-                 "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
-                 " --frames-in-flight 1   (MI355X, config B, one frame at a time: clean per-kernel durations)")
-kernel_stats("configE", tag + "_kernel_stats_configE_serial.txt",
-             "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline"
-             " --frames-in-flight 1 --gaussians 6000000 --width 3840 --height 2160   (MI355X, config E, one frame at a time)")
-
-pmc, fetch, write = counters("pmc"), counters("fetch"), counters("write")
-if pmc:
-    with open(os.path.join(dst, tag + "_pmc_counters.txt"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --pmc <counters> -- " + PMC_CMD + "  (MI355X, config B); three separate runs:\n"
-                "#   SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU "
-                "SQ_WAIT_ANY | FETCH_SIZE | WRITE_SIZE\n"
-                "# medians over the dispatches of the run.  FETCH_SIZE / WRITE_SIZE in KB.  SQ_*_CYCLES are quad-cycles; SQ_BUSY_CYCLES is summed "
-                "over 32 shader engines.\n")
-        f.write("%-30s %10s %10s %10s %12s %12s %10s %10s\n"
-                % ("kernel", "VALU_inst", "SALU_inst", "LDS_inst", "WAVE_CYCLES", "BUSY_CYCLES", "FETCH_KB", "WRITE_KB"))
-        order = sorted(pmc, key=lambda k: -mean(pmc[k]["SQ_INSTS_VALU"]))
-        for k in order:
-            c = pmc[k]
-            f.write("%-30s %10.3g %10.3g %10.3g %12.4g %12.4g %10.0f %10.0f\n"
-                    % (k, mean(c["SQ_INSTS_VALU"]), mean(c["SQ_INSTS_SALU"]), mean(c["SQ_INSTS_LDS"]),
-                       mean(c["SQ_WAVE_CYCLES"]), mean(c["SQ_BUSY_CYCLES"]), mean(fetch[k]["FETCH_SIZE"]),
-                       mean(write[k]["WRITE_SIZE"])))
-    print("wrote", tag + "_pmc_counters.txt")
-
-    b = bench_line(os.path.join(src, "bench_default.json")) or bench_line(os.path.join(src, "sweep_default.json"))
+CMD = "python tools/tune_sweep.py --no-prime --batches 1 <workload args>"
+workloads = {}
+pmc_txt = []
+for wl in [d for d in ("B", "C", "T", "E") if os.path.isdir(os.path.join(src, d))]:
+    kernel_stats(wl, "serial", f"{tag}_kernel_stats_{wl}_serial.txt",
+                 f"rocprofv3 --kernel-trace --stats --output-format csv -- {CMD} --fif 1   (MI355X, {NAMES[wl]}, one frame at a "
+                 "time: clean per-kernel durations; default blend = reference-exact)")
+    kernel_stats(wl, "default", f"{tag}_kernel_stats_{wl}_3inflight.txt",
+                 f"rocprofv3 --kernel-trace --stats --output-format csv -- {CMD} --fif 3   (MI355X, {NAMES[wl]}, 3 frames in "
+                 "flight like the default bench command; durations include contention from the other frames in flight)")
+    pmc, fetch, write, fast = counters(wl, "pmc"), counters(wl, "fetch"), counters(wl, "write"), counters(wl, "pmc_fast")
+    if not pmc:
+        continue
+    b = bench_line(os.path.join(src, wl, "serial", "bench.json"))
     cfg = b["config"] if b else {}
-    n, v, d = cfg.get("gaussians", 0), cfg.get("visible", 0), cfg.get("instances", 0)
+    n, v, d, w, h = (cfg.get(k, 0) for k in ("gaussians", "visible", "instances", "width", "height"))
     kernels = {}
-    for k in pmc:
-        e = {"fetch_kb": round(mean(fetch[k]["FETCH_SIZE"])), "write_kb": round(mean(write[k]["WRITE_SIZE"])),
-             # gfx950: FETCH_SIZE reports half of a wide coalesced stream (MI355X_MICROARCH.md); applied to the
-             # coalesced plane reads of k_preprocess only -- uncalibrated for 16-byte gathers
-             "fetch_scale": 2.0 if k == "gs::k_preprocess" else 1.0,
-             "valu_wave_insts": round(mean(pmc[k]["SQ_INSTS_VALU"]))}
-        kernels[k.replace("gs::", "")] = e
-    if "k_blend" in kernels and d:
-        kernels["k_blend"]["algorithmic_bytes"] = 40 * d + 16 * 1920 * 1080
-    if "k_preprocess" in kernels and n:
-        kernels["k_preprocess"]["algorithmic_bytes"] = n * 40 + v * 248
-    with open(os.path.join(dst, tag + "_pmc_hbm_traffic.json"), "w") as f:
-        json.dump({"_comment": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate runs) "
-                               "-- " + PMC_CMD + " on MI355X, "
-                               "config B.  KB per launch (median over the launches of the run), raw counter values; "
-                               "fetch_scale is the gfx950 correction (FETCH_SIZE reports half of a wide coalesced "
-                               "streaming read: applied to k_preprocess; the blend's 16-byte gathers are left raw). "
-                               "Infinity-Cache hits are counted as traffic.  valu_wave_insts = SQ_INSTS_VALU per launch.",
-                   "library_source_sha256": open(os.path.join(src, "source_hash.txt")).read().strip()
-                   if os.path.exists(os.path.join(src, "source_hash.txt")) else None,
-                   "gaussians": n, "width": 1920, "height": 1080, "kernels": kernels}, f, indent=1)
-    print("wrote", tag + "_pmc_hbm_traffic.json")
+    pmc_txt.append(f"## {NAMES[wl]}: N={n} V={v} D={d}")
+    pmc_txt.append("%-34s %10s %10s %10s %12s %12s %10s %10s"
+                   % ("kernel", "VALU_inst", "SALU_inst", "LDS_inst", "WAVE_CYCLES", "BUSY_CYCLES", "FETCH_KB", "WRITE_KB"))
+    for k in sorted(pmc, key=lambda k: -med(pmc[k]["SQ_INSTS_VALU"])):
+        c = pmc[k]
+        pmc_txt.append("%-34s %10.4g %10.4g %10.4g %12.4g %12.4g %10.0f %10.0f"
+                       % (k, med(c["SQ_INSTS_VALU"]), med(c["SQ_INSTS_SALU"]), med(c["SQ_INSTS_LDS"]), med(c["SQ_WAVE_CYCLES"]),
+                          med(c["SQ_BUSY_CYCLES"]), med(fetch[k]["FETCH_SIZE"]), med(write[k]["WRITE_SIZE"])))
+        kernels[k] = {"fetch_kb": round(med(fetch[k]["FETCH_SIZE"])), "write_kb": round(med(write[k]["WRITE_SIZE"])),
+                      # gfx950: FETCH_SIZE reports half of a wide coalesced stream (MI355X_MICROARCH.md); applied to the
+                      # coalesced plane reads of k_preprocess only -- uncalibrated for 16-byte gathers
+                      "fetch_scale": 2.0 if k.startswith("k_preprocess") else 1.0,
+                      "valu_wave_insts": round(med(pmc[k]["SQ_INSTS_VALU"])), "salu_wave_insts": round(med(pmc[k]["SQ_INSTS_SALU"]))}
+    for k in fast:  # the opt-in fast blend (exp 0, contraction): SQ counters only
+        if k.startswith("k_blend") and k not in kernels:
+            base = kernels.get("k_blend<2, false>", {})
+            kernels[k] = {"fetch_kb": base.get("fetch_kb", 0), "write_kb": base.get("write_kb", 0), "fetch_scale": 1.0,
+                          "valu_wave_insts": round(med(fast[k]["SQ_INSTS_VALU"])), "salu_wave_insts": round(med(fast[k]["SQ_INSTS_SALU"])),
+                          "note": "FETCH/WRITE taken from the default blend's run (same lists, same records)"}
+            pmc_txt.append("%-34s %10.4g %10.4g %10.4g %12.4g %12.4g   (opt-in fast blend; separate run)"
+                           % (k, med(fast[k]["SQ_INSTS_VALU"]), med(fast[k]["SQ_INSTS_SALU"]), med(fast[k]["SQ_INSTS_LDS"]),
+                              med(fast[k]["SQ_WAVE_CYCLES"]), med(fast[k]["SQ_BUSY_CYCLES"])))
+    for k in kernels:
+        if k.startswith("k_blend") and d:
+            kernels[k]["algorithmic_bytes"] = 40 * d + 16 * w * h
+        if k.startswith("k_preprocess") and n:
+            kernels[k]["algorithmic_bytes"] = n * 40 + v * 248
+    kind = cfg.get("scene", "S")
+    workloads[f"{kind}({n})@{w}x{h}"] = {"name": NAMES[wl], "gaussians": n, "visible": v, "instances": d, "width": w, "height": h,
+                                        "kernels": kernels}
 
-for name in ("bench_default", "bench_configE", "bench_configC_standin", "bench_default_hwexp", "bench_configE_sh16"):
-    b = bench_line(os.path.join(src, name + ".json"))
-    if b:
-        with open(os.path.join(dst, "%s_%s.json" % (tag, name)), "w") as f:
-            json.dump(b, f)
-            f.write("\n")
-        print("wrote", "%s_%s.json" % (tag, name), b["value"], b["unit"])
+if workloads:
+    with open(os.path.join(dst, tag + "_pmc_counters.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc <counters> -- " + CMD + " --fif 1 --frames 3 --warm 2  (MI355X); three separate runs per workload:\n"
+                "#   SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY | FETCH_SIZE | WRITE_SIZE\n"
+                "# medians over the dispatches of a run.  FETCH_SIZE / WRITE_SIZE in KB.  SQ_*_CYCLES are quad-cycles; SQ_BUSY_CYCLES is summed over 32 shader engines.\n")
+        f.write("\n".join(pmc_txt) + "\n")
+    with open(os.path.join(dst, tag + "_pmc_hbm_traffic.json"), "w") as f:
+        json.dump({"_comment": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate runs per workload) "
+                               "-- " + CMD + " --fif 1 --frames 3 --warm 2 on MI355X.  KB per launch (median over the launches of "
+                               "the run), raw counter values; fetch_scale is the gfx950 correction (FETCH_SIZE reports half of a wide "
+                               "coalesced streaming read: applied to k_preprocess; gathers are left raw).  Infinity-Cache hits are "
+                               "counted as traffic.  valu_wave_insts = SQ_INSTS_VALU per launch.",
+                   "library_source_sha256": open(os.path.join(src, "source_hash.txt")).read().strip(),
+                   "workloads": workloads}, f, indent=1)
+    print("wrote", tag + "_pmc_counters.txt,", tag + "_pmc_hbm_traffic.json", list(workloads))

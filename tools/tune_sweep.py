@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--fif", type=str, default="1,2,3,4,6")
     ap.add_argument("--quick", action="store_true", help="1 and 3 frames in flight, twice (A/B of library builds)")
     ap.add_argument("--sh16", action="store_true")
+    ap.add_argument("--scene", choices=["S", "T"], default="S")
+    ap.add_argument("--exp-mode", type=int, default=2, help="gs_set_exp_mode: 2 libm-exact (default), 0 polynomial, 1 v_exp_f32")
+    ap.add_argument("--contract", type=int, default=0, help="gs_set_blend_contraction")
     ap.add_argument("--warm", type=int, default=20, help="untimed frames ahead of every configuration")
     ap.add_argument("--no-prime", action="store_true", help="skip the initial 3-in-flight run (profiled runs: only the asked configurations launch)")
     ap.add_argument("--json-out", type=str, default="", help="write the last configuration's numbers as one JSON object")
@@ -39,17 +42,19 @@ def main():
     hip = ctypes.CDLL("libamdhip64.so")
     n, w, h = args.gaussians, args.width, args.height
     t0 = time.perf_counter()
-    cache = f"/tmp/gs_sweep_scene_{n}.npy"  # a second process of the same call (another library) reuses the scene
+    cache = f"/tmp/gs_sweep_scene_{args.scene}{n}.npy"  # a second process of the same call (another library) reuses the scene
     if os.path.exists(cache):
         rec = np.load(cache)
     else:
-        rec = pkg.synth.synth_records(n, seed=0, kind="S")
+        rec = pkg.synth.synth_records(n, seed=0, kind=args.scene)
         np.save(cache, rec)
     scene = pkg.Scene.from_records(rec, device=0)
     del rec
     if args.sh16:
         scene.quantize_sh()
     rend = pkg.Renderer(scene)
+    rend.set_exp_mode(args.exp_mode)
+    rend.set_blend_contraction(bool(args.contract))
     u = pkg.camera_uniforms(pkg.make_camera(), w, h)
     outs = []
     for _ in range(8):
@@ -100,7 +105,8 @@ def main():
                                                                     [float(x) for x in spans.split()])),
                            "config": {"gaussians": int(st.num_gaussians), "visible": int(st.num_visible),
                                       "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries),
-                                      "width": w, "height": h}}, f)
+                                      "width": w, "height": h, "scene": args.scene,
+                                      "exp_mode": args.exp_mode, "contract": args.contract}}, f)
                 f.write("\n")
         return float(np.median(fps))
 

@@ -44,6 +44,29 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
                     asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                                  "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (MODE >= 20 && MODE <= 24) {  // binary64 and conversions: what gs_expf_libm is made of
+                double d0 = a0, d1 = a1, d2 = a2, d3 = a3;
+                if (MODE == 20)
+                    asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
+                                 "v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5"
+                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"((double)m), "v"((double)c));
+                if (MODE == 21)
+                    asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                                 "v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4"
+                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"((double)m));
+                if (MODE == 22)
+                    asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
+                                 "v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4"
+                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"((double)c));
+                if (MODE == 23)  // f32 -> f64
+                    asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7\n"
+                                 "v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7"
+                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+                if (MODE == 24)  // f64 -> f32
+                    asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7\n"
+                                 "v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7"
+                                 : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+                a0 = (float)d0; a1 = (float)d1; a2 = (float)d2; a3 = (float)d3;
             } else if (MODE == 4) {  // 8 v_add_f32
                 a0 += c; a1 += c; a2 += c; a3 += c; a4 += c; a5 += c; a6 += c; a7 += c;
             } else if (MODE == 5) {  // 8 v_cndmask (select on compare) + cmp
@@ -84,6 +107,12 @@ int main() {
     run<7>("asm v_fma_f32", 1, 8);
     run<8>("asm v_exp_f32", 1, 8);
     run<5>("cmp+cndmask", 1, 16);
+    // binary64: 8 instructions of the kind per step, plus 4 cvt in + 4 cvt out of the harness (subtract the cvt rows)
+    run<20>("v_fma_f64 (+8cvt)", 1, 8);
+    run<21>("v_mul_f64 (+8cvt)", 1, 8);
+    run<22>("v_add_f64 (+8cvt)", 1, 8);
+    run<23>("v_cvt_f64_f32 (+8cvt)", 1, 8);
+    run<24>("v_cvt_f32_f64 (+8cvt)", 1, 8);
     run<9>("fma, lanes 0-31", 1, 8);
     run<10>("fma, lanes 32-63", 1, 8);
     run<11>("fma, even lanes", 1, 8);
