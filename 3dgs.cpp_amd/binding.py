@@ -55,7 +55,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_set_blend_contraction", "gs_get_timing_totals",
            "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_renderer_stream",
            "gs_dist_unique_id", "gs_dist_create", "gs_dist_rank", "gs_dist_world", "gs_dist_pose_count",
-           "gs_dist_broadcast_scene", "gs_dist_destroy"]
+           "gs_dist_broadcast_scene", "gs_dist_broadcast_scene_ex", "gs_dist_destroy"]
 
 
 class FrameStats(C.Structure):
@@ -356,10 +356,12 @@ class Dist:
     def pose_count(self, poses):
         return int(lib().gs_dist_pose_count(self._h, C.c_uint64(poses)))
 
-    def broadcast_scene(self, scene=None, root=0):
-        """Root passes its Scene and gets it back; the other ranks get a new Scene holding the received blob."""
+    def broadcast_scene(self, scene=None, root=0, copy_on_root=False):
+        """Root passes its Scene and gets it back (or, with copy_on_root, a new replica like every other rank); the other
+        ranks get a new Scene holding the received blob.  A quantised root scene arrives quantised."""
         out = C.c_void_p()
-        _check(lib().gs_dist_broadcast_scene(self._h, scene._h if scene is not None else None, C.c_int(root), C.byref(out)))
+        _check(lib().gs_dist_broadcast_scene_ex(self._h, scene._h if scene is not None else None, C.c_int(root),
+                                                C.c_uint(1 if copy_on_root else 0), C.byref(out)))
         if scene is not None and out.value == scene._h.value:
             return scene
         return Scene(out)

@@ -129,6 +129,16 @@ namespace {
 constexpr uint64_t kMaxGaussians = 1ull << 31;  // ids and counts are 32-bit on the device
 constexpr uint64_t kMaxInstances = (1ull << 30) - 4096;  // the per-tile lists live in one 4 GiB raw buffer
 
+void quantize_sh(gs_scene* s) {  // gs_scene_quantize_sh; also run on the receiving ranks of a quantised scene's broadcast
+    if (s->sh_half) return;
+    HIP_CHECK(hipSetDevice(s->device));
+    s->sh16.alloc(48 * static_cast<size_t>(s->n));
+    gs::launch_sh_to_half(s->blob, s->sh16.p, static_cast<uint32_t>(s->n), static_cast<uint32_t>(gs::blob_stride(s->n)), nullptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(nullptr));
+    s->sh_half = true;  // read when a frame is enqueued: frames already in flight keep reading the fp32 block, which stays
+}
+
 // Load-time host work (activation, AoS -> blob, PLY remapping) is embarrassingly parallel over Gaussians; the
 // reference does it on one thread, one 248-byte ifstream::read per Gaussian (GSScene.cpp:36-59).
 template <class F>
@@ -543,7 +553,9 @@ struct FrameSlot {
 
 struct gs_renderer {
     static constexpr int kMaxInFlight = 8;
-    static constexpr int kSlots = kMaxInFlight + 1;  // one more than can be in flight: the previous frame's events stay readable
+    // twice what can be in flight: the frame-interval statistic reads the events of `latest_done`, which with frames
+    // completing out of order across the sets may lie up to kMaxInFlight - 1 frames behind the oldest pending one
+    static constexpr int kSlots = 2 * kMaxInFlight;
 
     gs_scene* scene = nullptr;
     bool timing = true;
@@ -1134,13 +1146,7 @@ uint64_t gs_scene_num_vertices(const gs_scene* s) { return s ? s->n : 0; }
 int gs_scene_quantize_sh(gs_scene* s) {
     return guarded([&] {
         if (!s) throw Error(GS_ERR_INVALID, "null argument");
-        if (s->sh_half) return;
-        HIP_CHECK(hipSetDevice(s->device));
-        s->sh16.alloc(48 * static_cast<size_t>(s->n));
-        gs::launch_sh_to_half(s->blob, s->sh16.p, static_cast<uint32_t>(s->n), static_cast<uint32_t>(gs::blob_stride(s->n)), nullptr);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(nullptr));
-        s->sh_half = true;
+        quantize_sh(s);
     });
 }
 
@@ -1545,22 +1551,28 @@ uint64_t gs_dist_pose_count(const gs_dist* d, uint64_t poses) {
     return (poses - d->rank + d->world - 1) / d->world;
 }
 
-int gs_dist_broadcast_scene(gs_dist* d, gs_scene* mine, int root, gs_scene** out) {
+int gs_dist_broadcast_scene_ex(gs_dist* d, gs_scene* mine, int root, unsigned flags, gs_scene** out) {
     return guarded([&] {
         if (!d || !out) throw Error(GS_ERR_INVALID, "null argument");
         if (root < 0 || root >= d->world) throw Error(GS_ERR_INVALID, "root out of range");
         if (d->rank == root && !mine) throw Error(GS_ERR_INVALID, "the root rank must pass its scene");
         HIP_CHECK(hipSetDevice(d->device));
-        // (1) the Gaussian count, (2) the packed blob: 11 padded SoA planes + the SH block, one message
-        DevBuf<uint64_t> d_n;
-        d_n.alloc(1);
-        uint64_t n = d->rank == root ? mine->n : 0;
-        HIP_CHECK(hipMemcpyAsync(d_n.p, &n, sizeof n, hipMemcpyHostToDevice, d->stream));
-        nccl_check(rccl().Broadcast(d_n.p, d_n.p, 1, ncclUint64, root, d->comm, d->stream), "ncclBroadcast(count)");
-        HIP_CHECK(hipMemcpyAsync(&n, d_n.p, sizeof n, hipMemcpyDeviceToHost, d->stream));
+        // (1) a two-word header: the Gaussian count and the scene's storage flags (bit 0: SH kept as binary16 -- every replica
+        // must render from the same coefficients as the root), (2) the packed blob: 11 padded SoA planes + the SH block, one message
+        DevBuf<uint64_t> d_hdr;
+        d_hdr.alloc(2);
+        uint64_t hdr[2] = {d->rank == root ? mine->n : 0, d->rank == root && mine->sh_half ? 1ull : 0ull};
+        HIP_CHECK(hipMemcpyAsync(d_hdr.p, hdr, sizeof hdr, hipMemcpyHostToDevice, d->stream));
+        nccl_check(rccl().Broadcast(d_hdr.p, d_hdr.p, 2, ncclUint64, root, d->comm, d->stream), "ncclBroadcast(header)");
+        HIP_CHECK(hipMemcpyAsync(hdr, d_hdr.p, sizeof hdr, hipMemcpyDeviceToHost, d->stream));
         HIP_CHECK(hipStreamSynchronize(d->stream));
+        const uint64_t n = hdr[0];
         if (n >= kMaxGaussians) throw Error(GS_ERR_INVALID, "too many Gaussians (limit 2^31)");
-        if (d->rank == root) {
+        // the root normally keeps its own scene (in-place broadcast); with GS_DIST_COPY_ON_ROOT it receives into a fresh
+        // scene like every other rank (out-of-place broadcast: send buffer = its scene), so that the caller may release or
+        // keep editing the original -- and so that the receiving path can be exercised on a single GPU
+        const bool receive = d->rank != root || (flags & GS_DIST_COPY_ON_ROOT) != 0;
+        if (!receive) {
             nccl_check(rccl().Broadcast(mine->blob, mine->blob, gs::blob_floats(n), ncclFloat32, root, d->comm, d->stream),
                        "ncclBroadcast(scene)");
             HIP_CHECK(hipStreamSynchronize(d->stream));
@@ -1572,12 +1584,18 @@ int gs_dist_broadcast_scene(gs_dist* d, gs_scene* mine, int root, gs_scene** out
         s->n = n;
         s->owned_blob.alloc(gs::blob_floats(n));
         s->blob = s->owned_blob.p;
-        nccl_check(rccl().Broadcast(s->blob, s->blob, gs::blob_floats(n), ncclFloat32, root, d->comm, d->stream),
+        const float* send = d->rank == root ? mine->blob : s->blob;
+        nccl_check(rccl().Broadcast(send, s->blob, gs::blob_floats(n), ncclFloat32, root, d->comm, d->stream),
                    "ncclBroadcast(scene)");
         HIP_CHECK(hipStreamSynchronize(d->stream));
         s->finish_load();  // cov3D is recomputed locally: 24 B / Gaussian of arithmetic instead of 24 B over xGMI
+        if (hdr[1] & 1ull) quantize_sh(s.get());  // 96 B / Gaussian of local rounding instead of 96 B over xGMI
         *out = s.release();
     });
+}
+
+int gs_dist_broadcast_scene(gs_dist* d, gs_scene* mine, int root, gs_scene** out) {
+    return gs_dist_broadcast_scene_ex(d, mine, root, 0u, out);
 }
 
 void gs_dist_destroy(gs_dist* d) { delete d; }

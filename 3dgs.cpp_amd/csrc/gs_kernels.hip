@@ -32,6 +32,9 @@ namespace gs {
 #ifndef GS_L1_WORDLOOP
 #define GS_L1_WORDLOOP 1
 #endif
+#ifndef GS_PRE_SH_LDS
+#define GS_PRE_SH_LDS 1  // k_preprocess fetches the SH blocks of a wave's visible Gaussians with LDS-DMA, whole lines at a time
+#endif
 #define BLOCK 256
 
 // ---------------------------------------------------------------------------------------
@@ -170,6 +173,84 @@ struct PreUniforms {
 // 64 float4 with a plane stride of 68 (272 dwords = 16 mod 64: the cooperative reads of 16 consecutive lanes cover all
 // 64 banks once).
 constexpr int kPrePlane = 68, kPreStage = 3 * kPrePlane;
+#if GS_PRE_SH_LDS
+// ... and, ahead of that (the two uses alias: the SH blocks are consumed before the records are staged), the SH blocks of up
+// to 32 of the wave's visible Gaussians, fetched by LDS-DMA: 32 x 192 B = 384 float4 (+ 64 source-lane bytes)
+#ifndef GS_PRE_SH_HALF
+#define GS_PRE_SH_HALF 32
+#endif
+constexpr int kPreShHalf = GS_PRE_SH_HALF;
+constexpr int kPreWaveLds = kPreShHalf * 12 + 4;  // float4 units; >= kPreStage
+static_assert(kPreWaveLds >= kPreStage, "the record stage must fit the wave's LDS slab");
+#else
+constexpr int kPreWaveLds = kPreStage;
+#endif
+
+// preprocess.comp:73-108 compute_sh (degree 3 always; only .x clamped), the channel's terms accumulated in the shader's order.
+// SH(j, k) = coefficient j of channel k.  Written coefficient-major (all three channels take term j before any takes term
+// j + 1): per channel the sequence of operations is the shader's, and a source that lives in LDS can be consumed as it is read
+// (FENCE: a compiler barrier every few terms, so that the 48 reads are not all hoisted into registers at once).
+template <bool FENCE, class SH>
+__device__ __forceinline__ void sh_to_rgb(const SH& S, float x, float y, float z, float (&rgb)[3]) {
+    const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+    const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                C3_6 = -0.5900435899266435f;
+    float c[3];
+#define GS_SH_FENCE() do { if (FENCE) asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) :: "memory"); } while (0)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = SH_C0 * S(0, k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] -= SH_C1 * S(1, k) * y;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += SH_C1 * S(2, k) * z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] -= SH_C1 * S(3, k) * x;
+    GS_SH_FENCE();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C2_0 * S(4, k) * x * y;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C2_1 * S(5, k) * y * z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C2_2 * S(6, k) * (2.0f * z * z - x * x - y * y);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C2_3 * S(7, k) * z * x;
+    GS_SH_FENCE();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C2_4 * S(8, k) * (x * x - y * y);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C3_0 * S(9, k) * (3.0f * x * x - y * y) * y;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C3_1 * S(10, k) * x * y * z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C3_2 * S(11, k) * (4.0f * z * z - x * x - y * y) * y;
+    GS_SH_FENCE();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C3_3 * S(12, k) * z * (2.0f * z * z - 3.0f * x * x - 3.0f * y * y);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C3_4 * S(13, k) * x * (4.0f * z * z - x * x - y * y);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C3_5 * S(14, k) * (x * x - y * y) * z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] += C3_6 * S(15, k) * x * (x * x - 3.0f * y * y);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = c[k] + 0.5f;
+#undef GS_SH_FENCE
+    if (rgb[0] < 0.0f) rgb[0] = 0.0f;
+}
+struct ShFromRegs {
+    float v[48];
+    __device__ __forceinline__ float operator()(int j, int k) const { return v[j * 3 + k]; }
+};
+struct ShFromLds {
+    const float* p;
+    __device__ __forceinline__ float operator()(int j, int k) const { return p[j * 3 + k]; }
+};
+struct ShFromLds16 {
+    const uint16_t* p;
+    __device__ __forceinline__ float operator()(int j, int k) const { return __half2float(__ushort_as_half(p[j * 3 + k])); }
+};
 
 // One Gaussian per lane; `valid` = the lane has one (the last wave of the grid is ragged: every lane takes part in the
 // wave-cooperative parts).  stage: this wave's kPreStage float4 of LDS.
@@ -290,13 +371,70 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
     const bool vis = num_tiles != 0;
 
     // ---- the SH block of the visible Gaussians: 48 contiguous floats each (192 B = three 64-byte lines); only lanes
+    // that survived every cull need them, so SH traffic is 192 B per VISIBLE Gaussian.
+    float rgb[3] = {0.0f, 0.0f, 0.0f};
+#if GS_PRE_SH_LDS
+    // Fetched wave-cooperatively with LDS-DMA (global_load_lds_dwordx4: global -> LDS without passing through VGPRs): the
+    // visible lanes publish their lane numbers by rank; then lane l = 12 s + q of each instruction reads 16-byte chunk q of
+    // the (5 b + s)-th visible Gaussian -- twelve adjacent lanes cover one Gaussian's three whole lines, where a lane reading
+    // its own block issues twelve quarter-line requests -- and the DMA lays the chunks down lane-linearly, i.e. as the
+    // blocks, back to back, in rank order.  Each visible lane then reads its own block from LDS.  Up to 32 Gaussians per
+    // round (6 KiB per wave, aliased with the record stage below); a denser wave takes a second round.
+    const uint64_t vm_sh = __ballot(vis);
+    const uint32_t n_vis = (uint32_t)__popcll(vm_sh);
+    const uint32_t my_rank = (uint32_t)__popcll(vm_sh & ((1ull << lane) - 1ull));
+    uint8_t* const s_src = reinterpret_cast<uint8_t*>(stage + kPreShHalf * 12);  // [64] lane number of the r-th visible Gaussian
+    if (vis) s_src[my_rank] = (uint8_t)lane;
+    __builtin_amdgcn_wave_barrier();
+    const int chunks = sv.sh16 ? 6 : 12;                 // 16-byte chunks per Gaussian (binary16 storage: 96 B)
+    const uint32_t per_inst = sv.sh16 ? 10u : 5u;        // Gaussians per DMA instruction (60 of the 64 lanes)
+    const uint32_t slot = sv.sh16 ? lane / 6u : lane / 12u, q = sv.sh16 ? lane % 6u : lane % 12u;
+    const char* const sh_bytes = sv.sh16 ? reinterpret_cast<const char*>(sv.sh16) : reinterpret_cast<const char*>(blob + (size_t)P_SH * N);
+    const size_t sh_stride = sv.sh16 ? 96 : 192;
+    // LDS byte address of the wave's slab (the low half of a flat LDS pointer is the LDS offset), as a scalar: M0 takes it
+    const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)stage);
+    for (uint32_t half = 0; half * kPreShHalf < n_vis; ++half) {
+        const uint32_t first = half * kPreShHalf, last = min(n_vis, first + (uint32_t)kPreShHalf);
+        uint32_t dst = lds_base;
+        for (uint32_t g0 = first; g0 < last; g0 += per_inst, dst += per_inst * (uint32_t)sh_stride) {
+            const uint32_t g = g0 + slot;
+            if (lane < 60u && g < last) {
+                const uint32_t src_lane = s_src[g];
+                const char* gsrc = sh_bytes + (size_t)(i - lane + src_lane) * sh_stride + q * 16u;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (vis && my_rank >= first && my_rank < last) {
+            float dx = px - u.camera_position[0];
+            float dy = py - u.camera_position[1];
+            float dz = pz - u.camera_position[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float x = dx / len, y = dy / len, z = dz / len;
+            const float4* blk = stage + (size_t)(my_rank - first) * chunks;
+            if (sv.sh16) {  // binary16 storage, widened exactly
+                sh_to_rgb<true>(ShFromLds16{reinterpret_cast<const uint16_t*>(blk)}, x, y, z, rgb);
+            } else {
+                sh_to_rgb<true>(ShFromLds{reinterpret_cast<const float*>(blk)}, x, y, z, rgb);
+            }
+            av.depth[i] = depth;
+            av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1, (unsigned short)by1);
+        }
+        // every lane of this round has consumed its block (the values above depend on the reads): the next round's DMA, or
+        // the record stage, may overwrite the slab
+        __builtin_amdgcn_wave_barrier();
+    }
+#else
+    // ---- the SH block of the visible Gaussians: 48 contiguous floats each (192 B = three 64-byte lines); only lanes
     // that survived every cull need them, so SH traffic is 192 B per VISIBLE Gaussian
     // (A wave-cooperative fetch -- twelve lanes reading the twelve 16-byte chunks of one Gaussian, three full-line requests
     // instead of twelve quarter-line ones, the chunks handed to their owner through LDS -- measured 5 us SLOWER: 106 VGPRs
     // instead of 73 while chunks and coefficients are live together, four waves per SIMD instead of six.)
-    float rgb[3] = {0.0f, 0.0f, 0.0f};
     if (vis) {
-        float sh[48];
+        ShFromRegs sh;
         if (sv.sh16) {  // opt-in binary16 storage (gs_scene_quantize_sh): 96 B per visible Gaussian, widened exactly
             const uint4* __restrict__ shv = reinterpret_cast<const uint4*>(sv.sh16) + (size_t)i * 6;
 #pragma unroll
@@ -305,8 +443,8 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
                 const uint32_t wds[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    sh[8 * q + 2 * k + 0] = __half2float(__ushort_as_half((unsigned short)(wds[k] & 0xFFFFu)));
-                    sh[8 * q + 2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(wds[k] >> 16)));
+                    sh.v[8 * q + 2 * k + 0] = __half2float(__ushort_as_half((unsigned short)(wds[k] & 0xFFFFu)));
+                    sh.v[8 * q + 2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(wds[k] >> 16)));
                 }
             }
         } else {
@@ -314,51 +452,21 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 const float4 t = shv[q];
-                sh[4 * q + 0] = t.x;
-                sh[4 * q + 1] = t.y;
-                sh[4 * q + 2] = t.z;
-                sh[4 * q + 3] = t.w;
+                sh.v[4 * q + 0] = t.x;
+                sh.v[4 * q + 1] = t.y;
+                sh.v[4 * q + 2] = t.z;
+                sh.v[4 * q + 3] = t.w;
             }
         }
-        // :73-108 compute_sh (degree 3 always; only .x clamped)
         float dx = px - u.camera_position[0];
         float dy = py - u.camera_position[1];
         float dz = pz - u.camera_position[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float x = dx / len, y = dy / len, z = dz / len;
-        const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
-                    C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
-        const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
-                    C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
-                    C3_6 = -0.5900435899266435f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-#define S(j) sh[(j) * 3 + k]
-            float c = SH_C0 * S(0);
-            c -= SH_C1 * S(1) * y;
-            c += SH_C1 * S(2) * z;
-            c -= SH_C1 * S(3) * x;
-            c += C2_0 * S(4) * x * y;
-            c += C2_1 * S(5) * y * z;
-            c += C2_2 * S(6) * (2.0f * z * z - x * x - y * y);
-            c += C2_3 * S(7) * z * x;
-            c += C2_4 * S(8) * (x * x - y * y);
-            c += C3_0 * S(9) * (3.0f * x * x - y * y) * y;
-            c += C3_1 * S(10) * x * y * z;
-            c += C3_2 * S(11) * (4.0f * z * z - x * x - y * y) * y;
-            c += C3_3 * S(12) * z * (2.0f * z * z - 3.0f * x * x - 3.0f * y * y);
-            c += C3_4 * S(13) * x * (4.0f * z * z - x * x - y * y);
-            c += C3_5 * S(14) * (x * x - y * y) * z;
-            c += C3_6 * S(15) * x * (x * x - 3.0f * y * y);
-            c += 0.5f;
-#undef S
-            rgb[k] = c;
-        }
-        if (rgb[0] < 0.0f) rgb[0] = 0.0f;
-
+        sh_to_rgb<false>(sh, dx / len, dy / len, dz / len, rgb);
         av.depth[i] = depth;
         av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1, (unsigned short)by1);
     }
+#endif
     if (valid) av.tiles[i] = num_tiles;  // :128 / :176
 
     // ---- the 64-byte-strided record of every visible Gaussian.  Wave-cooperative: the records pass through LDS and four
@@ -386,7 +494,7 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
 }
 
 __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms pu, AttrView av) {
-    __shared__ float4 s_stage[BLOCK / WAVE][kPreStage];
+    __shared__ float4 s_stage[BLOCK / WAVE][kPreWaveLds];
     const gs_uniforms& u = pu.fp ? pu.fp->u : pu.u;  // uniform either way: scalar loads
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0 && pu.counters) {  // first kernel of the frame: the counters the later kernels accumulate into
@@ -777,6 +885,7 @@ __device__ __forceinline__ void walk_column(uint64_t col, uint32_t cur, __amdgpu
 constexpr int kL1Items = 1024;   // items per level-1 block: 16 chunks of 64, four per wave of a 256-thread workgroup
 constexpr int kL1Chunks = kL1Items / WAVE;
 constexpr int kL1PerWave = kL1Chunks / (BLOCK / WAVE);
+constexpr uint32_t kL1BigBox = 12;  // bins: beyond this a Gaussian's bin box is emitted by the whole wave, one bin per lane
 
 struct BinGrid {
     uint32_t tiles_x, tiles_y;  // tiles of the screen
@@ -872,8 +981,17 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
         const uint32_t box = s_box[w * kL1PerWave + j][lane];  // wave-private row: no barrier needed
         vis += (uint32_t)__popcll(__ballot(box != 0));
         const uint32_t x0 = box & 255u, y0 = (box >> 8) & 255u, x1 = (box >> 16) & 255u, y1 = box >> 24;
-        for (uint32_t y = y0; y < y1; ++y)
-            for (uint32_t x = x0; x < x1; ++x) atomicAdd(&s_hist[(y << a.g.grid_shift) | x], 1u);
+        // a splat that touches many bins (a screen-filling one touches all of them) would keep its lane in this loop for
+        // hundreds of rounds while the other 63 wait: boxes of more than kL1BigBox bins are spread over the whole wave below
+        const bool big = (x1 - x0) * (y1 - y0) > kL1BigBox;
+        if (!big)
+            for (uint32_t y = y0; y < y1; ++y)
+                for (uint32_t x = x0; x < x1; ++x) atomicAdd(&s_hist[(y << a.g.grid_shift) | x], 1u);
+        for (uint64_t bm = __ballot(big); bm != 0; bm &= bm - 1) {
+            const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)box, __ffsll((unsigned long long)bm) - 1);
+            const uint32_t bx0 = bb & 255u, by0 = (bb >> 8) & 255u, bw = ((bb >> 16) & 255u) - bx0, cells = bw * ((bb >> 24) - by0);
+            for (uint32_t c = lane; c < cells; c += WAVE) atomicAdd(&s_hist[((by0 + c / bw) << a.g.grid_shift) | (bx0 + c % bw)], 1u);
+        }
     }
     if (lane == 0 && vis) atomicAdd(&s_vis, vis);
     __syncthreads();
@@ -1081,23 +1199,40 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
         }
     }
     __syncthreads();
+    auto emit = [&](uint32_t bin, uint32_t k, uint32_t gid, ushort4 box) {
+        const uint32_t pos = atomicAdd(&s_cur[bin], 1u);
+        if (pos < a.capacity) {
+            uint32_t* const rec = a.cand + (size_t)kCandWords * pos;  // three adjacent dwords: one 12-byte store
+            rec[0] = k;
+            rec[1] = gid;
+            rec[2] = bin_local_box16(a.g, bin, box);
+        }
+    };
 #pragma unroll
     for (int j = 0; j < kL1PerWave; ++j) {
-        if (nt[j] == 0) continue;
         const uint32_t gid = blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
-        const uint32_t x0 = tb[j].x >> a.g.bin_shift, y0 = tb[j].y >> a.g.bin_shift;
-        const uint32_t x1 = ((tb[j].z - 1u) >> a.g.bin_shift) + 1u, y1 = ((tb[j].w - 1u) >> a.g.bin_shift) + 1u;
-        for (uint32_t y = y0; y < y1; ++y)
-            for (uint32_t x = x0; x < x1; ++x) {
-                const uint32_t bin = (y << a.g.grid_shift) | x;
-                const uint32_t pos = atomicAdd(&s_cur[bin], 1u);
-                if (pos < a.capacity) {
-                    uint32_t* const rec = a.cand + (size_t)kCandWords * pos;  // three adjacent dwords: one 12-byte store
-                    rec[0] = key[j];
-                    rec[1] = gid;
-                    rec[2] = bin_local_box16(a.g, bin, tb[j]);
-                }
-            }
+        uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        if (nt[j] != 0) {
+            x0 = tb[j].x >> a.g.bin_shift, y0 = tb[j].y >> a.g.bin_shift;
+            x1 = ((tb[j].z - 1u) >> a.g.bin_shift) + 1u, y1 = ((tb[j].w - 1u) >> a.g.bin_shift) + 1u;
+        }
+        const bool big = (x1 - x0) * (y1 - y0) > kL1BigBox;  // see k_l1_hist
+        if (!big)
+            for (uint32_t y = y0; y < y1; ++y)
+                for (uint32_t x = x0; x < x1; ++x) emit((y << a.g.grid_shift) | x, key[j], gid, tb[j]);
+        for (uint64_t bm = __ballot(big); bm != 0; bm &= bm - 1) {  // one Gaussian at a time, one bin per lane
+            const int src = __ffsll((unsigned long long)bm) - 1;
+            const uint32_t bx0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, src), by0 = (uint32_t)__builtin_amdgcn_readlane((int)y0, src);
+            const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)x1, src) - bx0;
+            const uint32_t cells = bw * ((uint32_t)__builtin_amdgcn_readlane((int)y1, src) - by0);
+            const uint32_t bkey = (uint32_t)__builtin_amdgcn_readlane((int)key[j], src);
+            const uint32_t bgid = (uint32_t)__builtin_amdgcn_readlane((int)gid, src);
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)tb[j].x | ((uint32_t)tb[j].y << 16)), src);
+            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)tb[j].z | ((uint32_t)tb[j].w << 16)), src);
+            const ushort4 bbox = make_ushort4((unsigned short)(blo & 0xFFFFu), (unsigned short)(blo >> 16), (unsigned short)(bhi & 0xFFFFu),
+                                              (unsigned short)(bhi >> 16));
+            for (uint32_t c = lane; c < cells; c += WAVE) emit(((by0 + c / bw) << a.g.grid_shift) | (bx0 + c % bw), bkey, bgid, bbox);
+        }
     }
 }
 
@@ -1187,8 +1322,8 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
         uint32_t tot_before, tot_mine;
         block_excl_scan<THREADS>(before, scratch, &tot_before);
         block_excl_scan<THREADS>(mine, scratch, &tot_mine);
-        c = tot_mine;
-        off = tot_before;
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot_mine);   // block-uniform: keep them scalar
+        off = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot_before);
     }
     if ((uint64_t)off + c > a.capacity) c = 0;  // candidate overflow (flagged by k_l1_scatter): the frame is re-run
     if (SORT && c > (uint32_t)MAXC) {
@@ -1456,6 +1591,17 @@ extern "C" int gs_debug_build_timing(unsigned long long* out /* [1024][8] */) {
 //      list order, and they store their ids at  tile start + chunk prefix + rank  -- consecutive addresses.
 // ROUNDS = candidates per thread: 4, 8 or 16 (4096 / 8192 / 16384 per bin; 48 / 72 / 136 KiB of LDS).
 // ---------------------------------------------------------------------------------------
+// A raw-buffer descriptor over [p, p + bytes) whose four words are provably scalar: the compiler "waterfalls" a buffer access
+// whose descriptor it cannot prove wave-uniform (a readfirstlane loop around the instruction with a full s_waitcnt: every
+// load serialised), and values that passed through LDS or a block scan look divergent to it however uniform they are.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t addr = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(addr >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane((int)bytes), 0x27000);
+}
+
 template <int ROUNDS>
 struct FastLayout {
     static constexpr int THREADS = 1024, NW = THREADS / WAVE, MAXC = THREADS * ROUNDS;
@@ -1498,8 +1644,11 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         uint32_t tb, tm;
         block_excl_scan<THREADS>((uint32_t)tid < bin ? v : 0u, scratch, &tb);
         block_excl_scan<THREADS>((uint32_t)tid == bin ? v : 0u, scratch, &tm);
-        c = tm;
-        off = tb;
+        // block-uniform by construction; telling the compiler so keeps everything derived from them (loop bounds, the
+        // record buffer's descriptor) in scalar registers -- a descriptor it believes divergent is "waterfalled": every
+        // load wrapped in a readfirstlane loop with a full s_waitcnt, i.e. serialised
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)tm);
+        off = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
     }
     if ((uint64_t)off + c > a.capacity) c = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
     if (c > (uint32_t)MAXC) {
@@ -1512,7 +1661,8 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // this bin's run of 12-byte records {key, id, box16} as a raw buffer: 32-bit offsets (one address register per load instead
     // of two) and the hardware's bounds check in place of branches (reads past the run return 0)
     typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    const __amdgpu_buffer_rsrc_t recs = __builtin_amdgcn_make_buffer_rsrc(a.cand + (size_t)kCandWords * off, 0, c * 12u, 0x27000);
+    uint32_t* const recs_ptr = a.cand + (size_t)kCandWords * off;
+#define recs uniform_rsrc(recs_ptr, c * 12u)  /* rebuilt from scalars at every use: see uniform_rsrc */
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
     const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
@@ -1596,23 +1746,29 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // than 64 equal depths, i.e. a degenerate scene): the records rewritten in id order, so that the stable passes alone
     // leave equal depths in id order
     for (int attempt = 0; c != 0 && attempt < 2; ++attempt) {
-        {   // ---- the bin's records, streamed: a thread's loads are all in flight together
-            uint32_t k[ROUNDS], b[ROUNDS];
+        // ---- the bin's records, streamed: eight loads per thread in flight together (sixteen would not leave the registers
+        // for it: a spilled address register is reloaded through the same counter the loads use, which serialises them)
+        uint32_t tid12 = (uint32_t)tid * 12u;
+        asm volatile("" : "+v"(tid12));  // opaque: or the sixteen offsets are hoisted out of the attempt loop, kept, and spilled
 #pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                const uint32_t e = r * THREADS + tid;
+        for (int h = 0; h < ROUNDS; h += 8) {
+            constexpr int HR = ROUNDS < 8 ? ROUNDS : 8;
+            uint32_t k[HR], b[HR];
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                const uint32_t e = (h + r) * THREADS + tid;
                 k[r] = 0;
                 b[r] = 0;
-                if (r < rounds) {
-                    const u32x3 rec = __builtin_amdgcn_raw_buffer_load_b96(recs, e * 12u, 0, 0);
+                if (h + r < rounds) {
+                    const u32x3 rec = __builtin_amdgcn_raw_buffer_load_b96(recs, tid12 + (uint32_t)(h + r) * (THREADS * 12u), 0, 0);
                     k[r] = rec.x;
                     b[r] = rec.z;
                 }
             }
 #pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                const uint32_t e = r * THREADS + tid;
-                if (r < rounds && e < c) {
+            for (int r = 0; r < HR; ++r) {
+                const uint32_t e = (h + r) * THREADS + tid;
+                if (h + r < rounds && e < c) {
                     s_key[e] = k[r];
                     s_pay[e] = e | (b[r] << 14);
                 }
@@ -1648,7 +1804,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         }
         if (too_long) s_flag = 1;
         __syncthreads();  // every read of the keys is done: the ids take their place
-        const bool redo = s_flag != 0;
+        const bool redo = __builtin_amdgcn_readfirstlane((int)s_flag) != 0;  // block-uniform (an LDS read is not, to the compiler)
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t e = r * THREADS + tid;
@@ -1706,6 +1862,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         if (tid == 0) s_flag = 0;
         __syncthreads();
     }
+#undef recs
     BUILD_T(3);
     // ---- the candidates' tile boxes inside the bin (they rode along in the payload), and the (chunk, tile) counts
     const uint32_t nch = (c + WAVE - 1) / WAVE;
@@ -1847,12 +2004,8 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
 // 8 waves per SIMD for the two smaller sizes, i.e. two workgroups per CU: needs <= 64 VGPRs and <= 80 SGPRs (a SIMD has
 // 800 SGPRs, allocated in sixteens plus sixteen per wave); the attribute wants a literal, hence three kernels
 template <int ROUNDS> __global__ void k_bin_fast(BuildArgs a);
-template <> __global__ __launch_bounds__(1024, 8) __attribute__((amdgpu_num_sgpr(80))) void k_bin_fast<4>(BuildArgs a) {
-    bin_fast_body<4>(a);
-}
-template <> __global__ __launch_bounds__(1024, 8) __attribute__((amdgpu_num_sgpr(80))) void k_bin_fast<8>(BuildArgs a) {
-    bin_fast_body<8>(a);
-}
+template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<4>(BuildArgs a) { bin_fast_body<4>(a); }
+template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<8>(BuildArgs a) { bin_fast_body<8>(a); }
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<16>(BuildArgs a) { bin_fast_body<16>(a); }
 
 static L1Args l1_args(const BinLaunch& b) {
@@ -2009,7 +2162,10 @@ __device__ __forceinline__ float min_q_rect(float c00, float c01, float c11, flo
     const float b = dy_lo > 0.0f ? dy_lo : dy_hi;  // the horizontal edge nearer to the centre
     const float s = fminf(fmaxf(r00 * b, dx_lo), dx_hi);
     const float qh = __builtin_fmaf(s, __builtin_fmaf(h00, s, c01 * b), h11 * b * b);
-    // any point of an edge bounds the true minimum from above: an inexact rcp only loosens the test
+    // The cull `mq > lim` needs mq to be a LOWER bound of q over the quadrant, and evaluating the parabola at an inexact
+    // minimiser (v_rcp_f32: 1 ULP) OVER-estimates its minimum -- by a second-order amount: q(t* + dt) - q(t*) = h dt^2 with
+    // dt/t* ~ 2^-23, i.e. ~1e-14 relative, which the caller's slack (4.8e-7 x the quadratic's largest terms + 0.1 %) absorbs
+    // many times over.  A coarser reciprocal or a smaller slack must revisit this.
     return in_x ? (in_y ? 0.0f : qh) : (in_y ? qv : fminf(qv, qh));
 }
 

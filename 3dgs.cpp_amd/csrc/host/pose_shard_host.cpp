@@ -76,7 +76,9 @@ int main(int argc, char** argv) {
     uint64_t mine = 0;
     for (uint64_t k = static_cast<uint64_t>(rank); k < poses; k += static_cast<uint64_t>(world), ++mine) {
         gs_camera cam{};
-        const double a = (5.0 * static_cast<double>(k)) * 3.14159265358979323846 / 180.0 / 2.0;
+        // operation for operation what dist.py::pose_quaternion does (math.radians(x) = x * (pi / 180)), so that both
+        // hosts hand the renderer the same float quaternion and the frames can be compared exactly
+        const double a = (5.0 * static_cast<double>(k)) * (3.14159265358979323846 / 180.0) / 2.0;
         cam.rotation[0] = static_cast<float>(std::cos(a));  // (w, x, y, z): yaw about world y
         cam.rotation[2] = static_cast<float>(std::sin(a));
         cam.fov = 45.0f;

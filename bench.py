@@ -109,6 +109,7 @@ def main():
                     help="opt-in fast blend as the benched mode: polynomial exp + the FMA contractions GLSL permits")
     ap.add_argument("--hw-exp", action="store_true", help="opt-in: the hardware's v_exp_f32 + contractions as the benched mode")
     ap.add_argument("--sh16", action="store_true", help="opt-in binary16 SH storage (gs_scene_quantize_sh)")
+    ap.add_argument("--dump-frames", default="", help="directory: every rank saves the frame of its pose (frame_rank<r>.npy) after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -266,6 +267,9 @@ def main():
             set_mode(m)
             frames_for_parity[m] = rend.render_host(u)[0]
     set_mode(mode)
+    if args.dump_frames:  # tests: every rank's pose against the checker (tests/test_gpu_dist.py)
+        os.makedirs(args.dump_frames, exist_ok=True)
+        np.save(os.path.join(args.dump_frames, f"frame_rank{rank}.npy"), rend.render_host(u)[0])
     if rank == 0:
         fps = world * args.steps / elapsed
         T = ((w + 15) // 16) * ((h + 15) // 16)

@@ -138,7 +138,10 @@ uint64_t gs_scene_num_vertices(const gs_scene* s);
 /* Opt-in storage quantisation (no reference counterpart; the reference keeps fp32 SH, GSScene.h:41-46): the 48 SH
  * coefficients of every Gaussian are rounded to binary16 (nearest even) once, and preprocess reads 96 B instead of
  * 192 B per visible Gaussian.  It CHANGES the scene: the result equals the reference pipeline run on the rounded
- * coefficients (what the parity tests feed the oracle), not on the original ones.  gs_scene_sh_bits: 32 or 16. */
+ * coefficients (what the parity tests feed the oracle), not on the original ones.  gs_scene_sh_bits: 32 or 16.
+ * The switch is read when a frame is enqueued: frames already in flight on the scene's renderers finish on the fp32 block
+ * (which stays allocated), later ones read the binary16 block -- call gs_synchronize first if no frame may straddle it.
+ * gs_dist_broadcast_scene replicates the setting. */
 int gs_scene_quantize_sh(gs_scene* s);
 int gs_scene_sh_bits(const gs_scene* s);
 /* Vertices [first, first + count) as GSScene::Vertex (60 floats each): spot checks of scenes too large to read back whole. */
@@ -249,6 +252,12 @@ int gs_dist_rank(const gs_dist* d);
 int gs_dist_world(const gs_dist* d);
 uint64_t gs_dist_pose_count(const gs_dist* d, uint64_t poses);  /* how many of `poses` poses this rank renders */
 int gs_dist_broadcast_scene(gs_dist* d, gs_scene* mine /* root only */, int root, gs_scene** out);
+/* The same with flags.  The header message carries, beside the count, the scene's storage flags: a root scene quantised
+ * with gs_scene_quantize_sh arrives quantised on every rank (rounded locally from the broadcast fp32 block), so that all
+ * replicas render from the same coefficients.  GS_DIST_COPY_ON_ROOT: the root, too, receives into a NEW scene (out-of-place
+ * broadcast from `mine`), which it owns beside `mine` -- every rank then runs the same receiving code. */
+#define GS_DIST_COPY_ON_ROOT 1u
+int gs_dist_broadcast_scene_ex(gs_dist* d, gs_scene* mine /* root only */, int root, unsigned flags, gs_scene** out);
 void gs_dist_destroy(gs_dist* d);
 
 #ifdef __cplusplus
