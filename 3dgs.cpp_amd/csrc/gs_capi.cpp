@@ -574,16 +574,16 @@ struct gs_renderer {
 
     gs_frame_stats last{};  // stats of the most recently retired frame
 
-    // How a frame's per-tile lists get their depth order.  level 0 / 1 / 2: bin-local -- the
-    // workgroup that builds a bin's lists orders its candidates in LDS first (up to 4096 / 8192 / 16384 per bin; 6 kernels
-    // per frame); level 3: global -- the V visible Gaussians are ordered first (12 more kernels; any bin size).
+    // How a frame's per-tile lists get their depth order.  level 0 .. 3: bin-local -- the
+    // workgroup that builds a bin's lists orders its candidates in LDS first (up to 4096 / 8192 / 12288 / 16384 per bin; 6
+    // kernels per frame); level 4: global -- the V visible Gaussians are ordered first (12 more kernels; any bin size).
     // sort_mode 0 = automatic: start at level 0; a bin that does not fit re-runs the frame at the level its size asks
     // for; after 32 frames that would have fitted the level below, go back down.
     int sort_mode = 0;           // 0 auto, 1 global depth order, 2 bin-local (forced: a bin beyond 16384 is an error)
     int level = 0;
     uint32_t frames_since_fallback = 0;
-    static constexpr int kGlobalLevel = 3;
-    static uint32_t level_limit(int lv) { return static_cast<uint32_t>(gs::kBinSortSmall) << lv; }
+    static constexpr int kGlobalLevel = gs::kBinSortLevels;
+    static uint32_t level_limit(int lv) { return gs::kBinSortLimit[lv]; }
     int frame_level() const { return sort_mode == 1 ? kGlobalLevel : level; }
     bool graph_mode = false;     // replay each frame as one captured HIP graph (gs_set_graph_mode)
     int exp_mode = 2;            // the blend's exp(): 2 libm's expf restated in binary64 (default), 0 pipeline polynomial, 1 hardware v_exp_f32 (gs_set_exp_mode)

@@ -1272,7 +1272,7 @@ constexpr int kBuildSlots = 16;  // chunks per fill round (one or four per wave)
 
 #ifdef GS_BUILD_TIMING
 // debug instrumentation (separate build, never the shipped library): per bin, the constant-rate clock at phase ends
-__device__ unsigned long long g_build_t[1024][8];
+__device__ unsigned long long g_build_t[1024][10];
 #define BUILD_T(i) do { if (threadIdx.x == 0) g_build_t[blockIdx.x][i] = wall_clock64(); } while (0)
 #else
 #define BUILD_T(i) do { } while (0)
@@ -1570,8 +1570,8 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
 }
 
 #ifdef GS_BUILD_TIMING
-extern "C" int gs_debug_build_timing(unsigned long long* out /* [1024][8] */) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_build_t), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? 0 : -1;
+extern "C" int gs_debug_build_timing(unsigned long long* out /* [1024][10] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_build_t), sizeof(unsigned long long) * 1024 * 10) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1589,7 +1589,7 @@ extern "C" int gs_debug_build_timing(unsigned long long* out /* [1024][8] */) {
 //      buffer (one atomic add), the tile ranges;
 //   5. fill: a wave takes a chunk; for each tile of the bin, a ballot of the lanes whose box covers it ranks them in
 //      list order, and they store their ids at  tile start + chunk prefix + rank  -- consecutive addresses.
-// ROUNDS = candidates per thread: 4, 8 or 16 (4096 / 8192 / 16384 per bin; 48 / 72 / 136 KiB of LDS).
+// ROUNDS = candidates per thread: 4, 8, 12 or 16 (4096 / 8192 / 12288 / 16384 per bin; 48 / 80 / 112 / 144 KiB of LDS).
 // ---------------------------------------------------------------------------------------
 // A raw-buffer descriptor over [p, p + bytes) whose four words are provably scalar: the compiler "waterfalls" a buffer access
 // whose descriptor it cannot prove wave-uniform (a readfirstlane loop around the instruction with a full s_waitcnt: every
@@ -1605,7 +1605,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, ui
 template <int ROUNDS>
 struct FastLayout {
     static constexpr int THREADS = 1024, NW = THREADS / WAVE, MAXC = THREADS * ROUNDS;
-    static constexpr int WCNT_WORDS = NW * 256 / 2;                       // u16 [16][256]
+    static constexpr int WCNT_WORDS = NW * 512 / 2;                       // u16 [16][512]: digits of up to nine bits
     static constexpr int MISC_WORDS = 64 + 64 + NW * 64;                  // t_cnt, t_cur, s_seg
     static constexpr int TAIL = WCNT_WORDS > MISC_WORDS ? WCNT_WORDS : MISC_WORDS;
     static constexpr int WORDS = 2 * MAXC + TAIL;
@@ -1619,7 +1619,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // while the order is being made: the sort's payload (slot in the bin's record run | box16 << 14) and the depth bits
     uint32_t* const s_pay = smem;
     uint32_t* const s_key = smem + MAXC;
-    uint16_t (*const s_wcnt)[256] = reinterpret_cast<uint16_t(*)[256]>(smem + 2 * MAXC);
+    uint16_t (*const s_wcnt)[512] = reinterpret_cast<uint16_t(*)[512]>(smem + 2 * MAXC);
     // once the order is final: the key area holds the ids, the payload area the 16-bit boxes and the chunk table, the
     // counter area the tile tables
     uint32_t* const s_id = smem + MAXC;                                                          // [MAXC]
@@ -1628,7 +1628,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     uint32_t* const t_cnt = smem + 2 * MAXC;                                                     // [64]
     uint32_t* const t_cur = t_cnt + 64;                                                          // [64]
     uint32_t (*const s_seg)[64] = reinterpret_cast<uint32_t(*)[64]>(t_cnt + 128);                // [16][64]
-    __shared__ uint32_t scratch[NW];
+    __shared__ uint32_t scratch[NW], scratch_hi[NW];
     __shared__ uint32_t s_seg0, s_flag;
     constexpr uint32_t kSlotMask = 0x3FFFu;  // MAXC <= 16384
 
@@ -1666,10 +1666,11 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
     const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
-    // One stable 8-bit LSD pass over (s_key, s_pay) in place, digit = byte `pass` of s_key.
-    auto radix_pass = [&](int pass) {
-        const int shift = pass * 8;
-        for (int k = tid; k < NW * 256 / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0;
+    // One stable LSD pass over (s_key, s_pay) in place: digit = `db` (<= 9) bits of (s_key - sub) at `shift`; the pass
+    // writes s_key - sub back (the first pass of a sort normalises the keys to the bin's smallest, the others pass sub = 0).
+    auto radix_pass = [&](int shift, int db, uint32_t sub) {
+        const uint32_t dmask = (1u << db) - 1u;
+        for (int k = tid; k < NW * 512 / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0;
         __syncthreads();  // also orders the previous pass's (or the load's) LDS writes before this pass's reads
         uint32_t key[ROUNDS], pay[ROUNDS], rank[ROUNDS];
 #pragma unroll
@@ -1681,20 +1682,22 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
                 const uint32_t e = wbase + r * WAVE + lane;
                 const bool ok = e < c;
                 if (ok) {
-                    key[r] = s_key[e];
+                    key[r] = s_key[e] - sub;
                     pay[r] = s_pay[e];
                 }
-                const uint32_t d = (key[r] >> shift) & 255u;
+                const uint32_t d = (key[r] >> shift) & dmask;
                 // lanes holding a valid element with my digit: AND over the bits of (ballot(bit) XNOR my bit)
                 const uint64_t okm = __ballot(ok);
                 uint32_t mlo = (uint32_t)okm, mhi = (uint32_t)(okm >> 32);
 #pragma unroll
-                for (int bit = 0; bit < 8; ++bit) {
-                    const uint32_t mine = (d >> bit) & 1u;
-                    const uint64_t b = __builtin_amdgcn_ballot_w64(mine != 0);
-                    const uint32_t splat = 0u - mine;
-                    mlo &= ~((uint32_t)b ^ splat);
-                    mhi &= ~((uint32_t)(b >> 32) ^ splat);
+                for (int bit = 0; bit < 9; ++bit) {
+                    if (bit < db) {  // wave-uniform
+                        const uint32_t mine = (d >> bit) & 1u;
+                        const uint64_t b = __builtin_amdgcn_ballot_w64(mine != 0);
+                        const uint32_t splat = 0u - mine;
+                        mlo &= ~((uint32_t)b ^ splat);
+                        mhi &= ~((uint32_t)(b >> 32) ^ splat);
+                    }
                 }
                 const uint64_t m = ((uint64_t)mhi << 32) | mlo;
                 uint32_t old = 0;
@@ -1710,7 +1713,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         __syncthreads();
         {   // per digit: prefix over the waves, then exclusive scan over the digits -> per-wave write cursors
             uint32_t cw[NW], cnt = 0;
-            if (tid < 256) {
+            if (tid < 512) {
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     cw[k] = s_wcnt[k][tid];
@@ -1719,7 +1722,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             }
             uint32_t all;
             uint32_t excl = block_excl_scan<THREADS>(cnt, scratch, &all);
-            if (tid < 256) {
+            if (tid < 512) {
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     s_wcnt[k][tid] = (uint16_t)excl;
@@ -1733,7 +1736,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             if (r < rounds) {
                 const uint32_t e = wbase + r * WAVE + lane;
                 if (e < c) {
-                    const uint32_t d = (key[r] >> shift) & 255u;
+                    const uint32_t d = (key[r] >> shift) & dmask;
                     const uint32_t pos = (uint32_t)s_wcnt[w][d] + rank[r];
                     s_key[pos] = key[r];
                     s_pay[pos] = pay[r];
@@ -1741,6 +1744,147 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             }
         }
         __syncthreads();
+    };
+    // smallest key and the span of the keys in LDS (block-uniform, scalar)
+    auto key_range = [&](uint32_t& kmin, uint32_t& span) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            if (r < rounds && e < c) {
+                const uint32_t k = s_key[e];
+                lo = min(lo, k);
+                hi = max(hi, k);
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, WAVE));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, WAVE));
+        }
+        __syncthreads();  // scratch reuse; also: the LDS writes of the load are visible
+        if (lane == 0) {
+            scratch[w] = lo;
+            scratch_hi[w] = hi;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            lo = min(lo, scratch[k]);
+            hi = max(hi, scratch_hi[k]);
+        }
+        kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+        span = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi) - kmin;
+    };
+    // Order (s_key, s_pay) by s_key with stable LSD passes: the keys are normalised to the smallest of them, which leaves
+    // `bits` significant bits (25 or so for the depths of one bin of a frame: three passes of nine bits)
+    auto sort_by_key_lsd = [&](uint32_t kmin, uint32_t span) {
+        const int bits = span ? 32 - __builtin_clz(span) : 0;
+        const int npass = (bits + 8) / 9;
+        const int db = npass ? (bits + npass - 1) / npass : 0;
+#pragma unroll 1
+        for (int pass = 0; pass < npass; ++pass) radix_pass(pass * db, db, pass == 0 ? kmin : 0u);
+        return npass ? kmin : 0u;  // what the stored keys are short of the originals
+    };
+    // The usual case, in two steps instead of three or four passes: (1) the keys' top twelve significant bits cut the bin into
+    // 4096 buckets (a counting scatter with LDS atomics: the order inside a bucket does not matter yet), (2) every element
+    // counts the elements of its bucket that precede it -- smaller key, or equal key and earlier position -- and moves to
+    // bucket start + that count.  Buckets hold two or three elements when the depths are spread over the bin's range; when
+    // they are not (a bucket of more than kMsdBucketMax: the candidates of a wall seen face on) the stable passes take over.
+    // Equal keys end up adjacent in an arbitrary order either way: the tie step below puts them in id order.
+    constexpr uint32_t kMsdBuckets = 4096, kMsdBucketMax = 64, kMsdPer = kMsdBuckets / THREADS;
+    uint32_t* const m_cnt = smem + 2 * MAXC;                                                  // [4096] u16, two to a word
+    uint16_t* const m_start = reinterpret_cast<uint16_t*>(smem + 2 * MAXC + kMsdBuckets / 2);  // [4096] u16 bucket starts
+    static_assert(kMsdBuckets * 4 <= L::TAIL * 4, "the bucket tables live in the counters' area");
+    auto sort_by_key_msd = [&](uint32_t kmin, uint32_t span) -> bool {
+        const int bits = 32 - __builtin_clz(span);  // span != 0
+        const int sh = bits > 12 ? bits - 12 : 0;
+        for (uint32_t k = tid; k < kMsdBuckets / 2; k += THREADS) m_cnt[k] = 0;
+        __syncthreads();
+        uint32_t key[ROUNDS], pay[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            key[r] = 0;
+            pay[r] = 0;
+            if (r < rounds && e < c) {
+                key[r] = s_key[e];
+                pay[r] = s_pay[e];
+                const uint32_t b = (key[r] - kmin) >> sh;
+                atomicAdd(&m_cnt[b >> 1], 1u << (16u * (b & 1u)));  // a bucket holds <= 16384: no carry between the halves
+            }
+        }
+        __syncthreads();
+        {   // thread t owns buckets 4 t .. 4 t + 3: their starts, and the counters back to zero (they become cursors)
+            const uint2 w2 = reinterpret_cast<const uint2*>(m_cnt)[tid];
+            const uint32_t v0 = w2.x & 0xFFFFu, v1 = w2.x >> 16, v2 = w2.y & 0xFFFFu, v3 = w2.y >> 16;
+            uint32_t all;
+            uint32_t excl = block_excl_scan<THREADS>(v0 + v1 + v2 + v3, scratch, &all);
+            if (max(max(v0, v1), max(v2, v3)) > kMsdBucketMax) s_flag = 2;  // (every writer stores the same value)
+            reinterpret_cast<uint2*>(m_cnt)[tid] = make_uint2(0u, 0u);
+            ushort4 st;
+            st.x = (unsigned short)excl;
+            st.y = (unsigned short)(excl + v0);
+            st.z = (unsigned short)(excl + v0 + v1);
+            st.w = (unsigned short)(excl + v0 + v1 + v2);
+            reinterpret_cast<ushort4*>(m_start)[tid] = st;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane((int)s_flag) == 2) {  // a crowded bucket: nothing has moved yet
+            __syncthreads();
+            if (tid == 0) s_flag = 0;
+            return false;
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            if (r < rounds && e < c) {
+                const uint32_t b = (key[r] - kmin) >> sh;
+                const uint32_t old = atomicAdd(&m_cnt[b >> 1], 1u << (16u * (b & 1u)));
+                const uint32_t pos = (uint32_t)m_start[b] + ((old >> (16u * (b & 1u))) & 0xFFFFu);
+                s_key[pos] = key[r];
+                s_pay[pos] = pay[r];
+            }
+        }
+        __syncthreads();
+        uint32_t dst[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            dst[r] = 0xFFFFFFFFu;
+            if (r < rounds && e < c) {
+                const uint32_t k = s_key[e];
+                pay[r] = s_pay[e];
+                key[r] = k;
+                const uint32_t b = (k - kmin) >> sh;
+                const uint32_t j0 = m_start[b], j1 = b + 1 < kMsdBuckets ? (uint32_t)m_start[b + 1] : c;
+                uint32_t before = 0;
+                for (uint32_t j = j0; j < j1; ++j) {
+                    const uint32_t kj = s_key[j];
+                    before += (kj < k || (kj == k && j < e)) ? 1u : 0u;
+                }
+                dst[r] = j0 + before;
+            }
+        }
+        __syncthreads();  // every read of the bucketed order is done
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            if (dst[r] != 0xFFFFFFFFu) {
+                s_key[dst[r]] = key[r];
+                s_pay[dst[r]] = pay[r];
+            }
+        __syncthreads();
+        return true;
+    };
+    // returns what the stored keys are short of the originals (the LSD passes normalise them; equality is what matters later)
+    auto sort_by_key = [&](bool try_msd) -> uint32_t {
+        uint32_t kmin, span;
+        key_range(kmin, span);
+        if (span == 0) return 0u;  // all keys equal: nothing to order
+        if constexpr (ROUNDS <= 12) {  // (sixteen elements per thread do not leave the registers for the second step)
+            if (try_msd && sort_by_key_msd(kmin, span)) return 0u;
+        }
+        return sort_by_key_lsd(kmin, span);
     };
     // attempt 0: the records as level 1 left them (any order inside a block's run).  attempt 1 (only after a run of more
     // than 64 equal depths, i.e. a degenerate scene): the records rewritten in id order, so that the stable passes alone
@@ -1750,9 +1894,9 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         // for it: a spilled address register is reloaded through the same counter the loads use, which serialises them)
         uint32_t tid12 = (uint32_t)tid * 12u;
         asm volatile("" : "+v"(tid12));  // opaque: or the sixteen offsets are hoisted out of the attempt loop, kept, and spilled
+        constexpr int HR = ROUNDS <= 8 ? ROUNDS : ROUNDS / 2;  // 4, 8, 6, 8
 #pragma unroll
-        for (int h = 0; h < ROUNDS; h += 8) {
-            constexpr int HR = ROUNDS < 8 ? ROUNDS : 8;
+        for (int h = 0; h < ROUNDS; h += HR) {
             uint32_t k[HR], b[HR];
 #pragma unroll
             for (int r = 0; r < HR; ++r) {
@@ -1775,8 +1919,8 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             }
         }
         if (attempt == 0) BUILD_T(2);
-#pragma unroll 1
-        for (int pass = 0; pass < 4; ++pass) radix_pass(pass);
+        sort_by_key(attempt == 0);
+        if (attempt == 0) BUILD_T(8);
         // ---- ties.  Candidates of equal depth must follow each other by Gaussian id (what the reference's stable sort of
         // (tile, depth) keys over index-ordered input gives).  Equal keys are adjacent now.  The element that STARTS a run of
         // equal keys measures the run (at most 64 more); all elements fetch their ids (a gather inside the bin's own record
@@ -1811,6 +1955,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             if (r < rounds && e < c) s_id[e] = my_id[r];
         }
         __syncthreads();
+        if (attempt == 0) BUILD_T(9);
         if (!redo) {
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
@@ -1835,8 +1980,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         }
         // ---- a long run of equal depths: order the bin by id (the ids sit in the key area: four more passes), rewrite its
         // records in that order and start over; the second attempt needs no tie handling
-#pragma unroll 1
-        for (int pass = 0; pass < 4; ++pass) radix_pass(pass);
+        const uint32_t id_base = sort_by_key(false);
         uint32_t nk[ROUNDS], ni[ROUNDS], nb[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
@@ -1845,7 +1989,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             if (r < rounds && e < c) {
                 const uint32_t pw = s_pay[e];
                 nk[r] = __builtin_amdgcn_raw_buffer_load_b32(recs, (pw & kSlotMask) * 12u, 0, 0);
-                ni[r] = s_id[e];
+                ni[r] = s_id[e] + id_base;
                 nb[r] = pw >> 14;
             }
         }
@@ -2006,6 +2150,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
 template <int ROUNDS> __global__ void k_bin_fast(BuildArgs a);
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<4>(BuildArgs a) { bin_fast_body<4>(a); }
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<8>(BuildArgs a) { bin_fast_body<8>(a); }
+template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<12>(BuildArgs a) { bin_fast_body<12>(a); }
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<16>(BuildArgs a) { bin_fast_body<16>(a); }
 
 static L1Args l1_args(const BinLaunch& b) {
@@ -2079,6 +2224,7 @@ hipError_t bin_prepare_device() {  // once per device (gs_renderer::init)
     hipError_t e = build_prepare<4, 1024, true>();
     if (e == hipSuccess) e = build_prepare<16, 1024, true>();
     if (e == hipSuccess) e = fast_prepare<8>();
+    if (e == hipSuccess) e = fast_prepare<12>();
     if (e == hipSuccess) e = fast_prepare<16>();
     return e;
 }
@@ -2103,10 +2249,11 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
     a.counters = b.counters;
     a.capacity = b.capacity;
     const uint32_t bins = b.bins_x * b.bins_y;  // on-screen bins: the kernels map the block index onto the padded grid
-    const bool sort = level < 3;
+    const bool sort = level < kBinSortLevels;
     if (sort && b.bin_shift <= 3) {  // bins of 4 x 4 or 8 x 8 tiles: the all-in-LDS kernel, sized by the level
         if (level == 0) hipLaunchKernelGGL(k_bin_fast<4>, dim3(bins), dim3(1024), FastLayout<4>::WORDS * sizeof(uint32_t), s, a);
         else if (level == 1) hipLaunchKernelGGL(k_bin_fast<8>, dim3(bins), dim3(1024), FastLayout<8>::WORDS * sizeof(uint32_t), s, a);
+        else if (level == 2) hipLaunchKernelGGL(k_bin_fast<12>, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
         else hipLaunchKernelGGL(k_bin_fast<16>, dim3(bins), dim3(1024), FastLayout<16>::WORDS * sizeof(uint32_t), s, a);
     } else if (b.bin_shift <= 3) {
         launch_build<1>(a, sort, bins, s);
