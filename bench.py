@@ -185,7 +185,7 @@ def main():
     # the W warm-up steps above are the contract's; the clocks of an idle chip need longer than a few milliseconds to
     # come up (round 2: the first timed batch ran at a ninth of the median), so untimed K-step batches follow until two
     # consecutive ones agree within 10 % (every rank runs the same count: the decision is made on the max over ranks)
-    prev = None
+    prev, stable = None, 0
     for _ in range(40):
         sync_all()
         tw = time.perf_counter()
@@ -197,7 +197,8 @@ def main():
             t = torch.tensor([dtw], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtw = float(t.item())
-        if prev is not None and abs(dtw - prev) <= 0.1 * min(dtw, prev):
+        stable = stable + 1 if prev is not None and abs(dtw - prev) <= 0.05 * min(dtw, prev) else 0
+        if stable >= 2:  # three consecutive batches within 5 % of each other
             break
         prev = dtw
     sync_all()
@@ -318,7 +319,7 @@ def main():
             # are the median batch, spread = interquartile range / median over the batches
             "timed": {"batches": len(batch_s), "seconds": round(float(np.sum(batch_s)), 4),
                       "batch_ms": {"min": round(1e3 * min(batch_s), 4), "median": round(1e3 * elapsed, 4),
-                                   "max": round(1e3 * max(batch_s), 4)},
+                                   "max": round(1e3 * max(batch_s), 4), "each": [round(1e3 * b, 2) for b in batch_s]},
                       "spread": round(spread, 4) if spread is not None else None},
             # distribution of the per-frame time over the timed region (median + p5/p95), rank 0
             "frame_ms": ({"p5": round(float(np.percentile(intervals, 5)), 4), "p50": round(float(np.percentile(intervals, 50)), 4),
