@@ -32,6 +32,9 @@ namespace gs {
 #ifndef GS_L1_WORDLOOP
 #define GS_L1_WORDLOOP 1
 #endif
+#ifndef GS_BLEND_ROWMASK
+#define GS_BLEND_ROWMASK 0  // experiment (round-2 verdict item 9): per (entry, quadrant) row intervals ANDed into the exec mask
+#endif
 #ifndef GS_PRE_SH_LDS
 #define GS_PRE_SH_LDS 1  // k_preprocess fetches the SH blocks of a wave's visible Gaussians with LDS-DMA, whole lines at a time
 #endif
@@ -2346,7 +2349,7 @@ __device__ __forceinline__ float gs_exp_blend(float x) {
 // operation in binary64 with the fused operations of the x86-64 FMA build -- so that the blend can be bit-identical to the
 // reference's shader text compiled for the CPU (the test suite's checker), whose exp() is libm's.  Restated from the published algorithm,
 // the table generated (2^(i/32) correctly rounded, exponent pre-subtracted), and PINNED by tests/test_expf_libm.py: equal to
-// this container's libm expf on every binary32 in [-87, 0] (1.1e9 values).  10 binary64 operations (half rate on gfx950) + one
+// this container's libm expf on every binary32 <= 0 (2.1e9 values).  9 binary64 operations (half rate on gfx950) + one
 // LDS read: ~23 issue slots against 10 for the polynomial.  Valid for the blend's range (x <= 0, results used for x >= -7).
 __device__ const uint64_t kExpfTab[32] = {
     0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
@@ -2367,13 +2370,16 @@ __device__ __forceinline__ float gs_expf_libm(float x, const uint2* __restrict__
     uint2 t = tab[ki & 31u];
     t.y += ki << 15;                                        // t += ki << 47: the exponent of 2^(k/32)
     const double sc = __longlong_as_double((long long)(((uint64_t)t.y << 32) | t.x));
-    // z = fma(C0, r, C1) as one VOP3 v_fma_f64 (left to itself the compiler copies C1 and uses the two-address v_fmac_f64)
-    double z;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(z) : "s"(C0), "v"(r), "v"(C1));
-    const double r2 = r * r;
-    double y = __builtin_fma(C2, r, 1.0);
-    y = __builtin_fma(z, r2, y);
-    y = y * sc;
+    // glibc evaluates  z = C0 r + C1;  y = C2 r + 1;  y = z r^2 + y;  y = y s  (five operations).  Here the same cubic times the
+    // same s in four:  q = (C0 r + C1) r + C2;  y = q (r s) + s.  The two differ in the last bits of the binary64 value, never
+    // in its rounding to binary32: tests/test_expf_libm.py runs this very sequence against libm's expf on every binary32 <= 0
+    // (IEEE binary64 operations give the same bits on the host as on the device).  q's first fma is written as one VOP3
+    // v_fma_f64 (left to itself the compiler copies C1 and uses the two-address v_fmac_f64).
+    double q0, q;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q0) : "s"(C0), "v"(r), "v"(C1));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(q0), "v"(r), "v"(C2));
+    const double rs = r * sc;
+    const double y = __builtin_fma(q, rs, sc);
     return (float)y;
 }
 
@@ -2488,7 +2494,30 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
             // contractions) while the per-pixel body loses the -0.5 multiply
             s_rec[w][0][lane] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
             s_rec[w][1][lane] = cur.uv;
+#if GS_BLEND_ROWMASK
+            // Experiment: the rows of the 8 x 8 block on which power >= -lim can hold for this entry (the same convex-quadratic
+            // bound as min_q_rect, row by row, with the same slack), as a 64-bit lane mask parked beside the record.
+            uint32_t rm_lo = 0, rm_hi = 0;
+            if (keep) {
+                const float h00 = 0.5f * cur.co.x, h11 = 0.5f * cur.co.z, r00 = -cur.co.y * __builtin_amdgcn_rcpf(cur.co.x);
+                const float dx_lo = cur.uv.x - (rx0 + 7.0f), dx_hi = cur.uv.x - rx0;
+                const float ax = fmaxf(fabsf(dx_lo), fabsf(dx_hi));
+#pragma unroll
+                for (int y = 0; y < 8; ++y) {
+                    const float dyr = cur.uv.y - (ry0 + (float)y);
+                    const float t = fminf(fmaxf(r00 * dyr, dx_lo), dx_hi);
+                    const float qrow = __builtin_fmaf(t, __builtin_fmaf(h00, t, cur.co.y * dyr), h11 * dyr * dyr);
+                    const float magr = __builtin_fmaf(0.5f * fabsf(cur.co.x) * ax, ax,
+                                                      __builtin_fmaf(0.5f * fabsf(cur.co.z) * dyr, dyr, fabsf(cur.co.y) * ax * fabsf(dyr)));
+                    const bool row_ok = !(qrow > __builtin_fmaf(magr, 4.8e-7f, lim));  // NaN -> keep
+                    const uint32_t byte = row_ok ? 0xFFu : 0u;
+                    if (y < 4) rm_lo |= byte << (8 * y); else rm_hi |= byte << (8 * (y - 4));
+                }
+            }
+            s_rec[w][2][lane] = make_float4(cur.b, -lim, __uint_as_float(rm_lo), __uint_as_float(rm_hi));
+#else
             s_rec[w][2][lane] = make_float4(cur.b, -lim, 0.0f, 0.0f);
+#endif
 
             while (bm) {
                 const int k = __ffsll((unsigned long long)bm) - 1;
@@ -2505,6 +2534,26 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                 // all ten floats in one LDS round trip: without this the compiler sinks the loads of o, r, g, b
                 // behind the exp() branch, where 94 % of the pairs then pay a second LDS latency
                 asm volatile("" : "+v"(co.w), "+v"(uv.z), "+v"(uv.w), "+v"(bp.x));
+#if GS_BLEND_ROWMASK
+                const uint64_t rows = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bp.w)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bp.z));
+                const uint64_t alive_e = alive & rows;
+                if (alive_e == 0) continue;
+                float power = 1.0f;  // lanes outside the rows: skipped like power > 0
+                if (__builtin_amdgcn_inverse_ballot_w64(alive_e)) {
+                    const float dx = uv.x - fx;
+                    const float dy = uv.y - fy;
+                    if (CONTRACT) {
+                        const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);
+                        power = __builtin_fmaf(co.y * dx, dy, s);
+                    } else {
+                        const float s = co.x * dx * dx + co.z * dy * dy;
+                        power = s + co.y * dx * dy;
+                    }
+                }
+                const uint64_t m1 = alive_e & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                    __builtin_amdgcn_ballot_w64(!(power < bp.y));
+#else
                 const float dx = uv.x - fx;
                 const float dy = uv.y - fy;
                 // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
@@ -2519,6 +2568,7 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                 // power <= 0 is false for NaN: a NaN power skips the entry (the pipeline's definition)
                 const uint64_t m1 = alive & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                     __builtin_amdgcn_ballot_w64(!(power < bp.y));
+#endif
                 if (m1 != 0) {
                     STAT_ADD(4, 1);                   // pairs reaching exp
                     STAT_ADD(5, __popcll(m1));        // lanes needing exp

@@ -145,6 +145,30 @@ float gso_expf_libm(float x) {
     y = y * sc;
     return (float)y;
 }
+/* The same function as the HIP kernels evaluate it (gs_expf_libm in gs_kernels.hip): the cubic and the scale in FOUR
+ * binary64 operations -- q = (C0 r + C1) r + C2;  y = q (r s) + s -- instead of glibc's five.  The binary64 values differ in
+ * their last bits, their roundings to binary32 never do: gso_expf_device_mismatches counts the binary32 inputs on which
+ * this sequence and this machine's libm differ, and tests/test_expf_libm.py requires 0 over every binary32 <= 0. */
+float gso_expf_device(float x) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0,
+                 C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    if (x < -0x1.9fe368p6f) return 0.0f; /* (the kernels never ask: power >= -lim there) */
+    const double xd = (double)x;
+    double kd = fma(InvLn2N, xd, SHIFT);
+    uint64_t ki;
+    memcpy(&ki, &kd, 8);
+    kd = kd - SHIFT;
+    const double r = fma(InvLn2N, xd, -kd);
+    uint64_t t = k_expf_tab[ki & 31u] + (ki << 47);
+    double sc;
+    memcpy(&sc, &t, 8);
+    double q = fma(C0, r, C1);
+    q = fma(q, r, C2);
+    const double rs = r * sc;
+    const double y = fma(q, rs, sc);
+    return (float)y;
+}
 /* bulk form for the exhaustive pin: out[i] = gso_expf_libm(bits -> float of first + i) */
 void gso_expf_libm_range(uint32_t first_bits, uint64_t count, float* out) {
 #pragma omp parallel for
@@ -157,6 +181,26 @@ void gso_expf_libm_range(uint32_t first_bits, uint64_t count, float* out) {
 }
 /* count of binary32 values with bit patterns first_bits .. first_bits + count - 1 on which gso_expf_libm and this
  * machine's libm expf differ (the pin itself, without moving 4 GB through Python) */
+uint64_t gso_expf_device_mismatches(uint32_t first_bits, uint64_t count, uint32_t* first_bad_bits) {
+    uint64_t bad = 0;
+    uint32_t first_bad = 0xFFFFFFFFu;
+#pragma omp parallel for reduction(+ : bad) reduction(min : first_bad)
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        uint32_t b = first_bits + (uint32_t)i, ua, ub;
+        float x, a, c;
+        memcpy(&x, &b, 4);
+        a = gso_expf_device(x);
+        c = expf(x);
+        memcpy(&ua, &a, 4);
+        memcpy(&ub, &c, 4);
+        if (ua != ub) {
+            ++bad;
+            if (b < first_bad) first_bad = b;
+        }
+    }
+    if (first_bad_bits) *first_bad_bits = first_bad;
+    return bad;
+}
 uint64_t gso_expf_libm_mismatches(uint32_t first_bits, uint64_t count, uint32_t* first_bad_bits) {
     uint64_t bad = 0;
     uint32_t first_bad = 0xFFFFFFFFu;

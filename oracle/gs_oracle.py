@@ -44,6 +44,7 @@ def lib():
         _LIB.gso_expf_libm.restype = C.c_float
         _LIB.gso_expf_libm.argtypes = [C.c_float]
         _LIB.gso_expf_libm_mismatches.restype = C.c_uint64
+        _LIB.gso_expf_device_mismatches.restype = C.c_uint64
         _LIB.gso_render_frame.restype = C.c_int
         _LIB.gso_load_ply.restype = C.c_int
         _LIB.gso_num_threads.restype = C.c_int
@@ -192,6 +193,13 @@ def expf_libm_mismatches(first_bits, count):
     """(# of binary32 bit patterns in [first_bits, first_bits + count) where gso_expf_libm != this machine's expf, first)"""
     bad = C.c_uint32(0)
     n = lib().gso_expf_libm_mismatches(C.c_uint32(first_bits), C.c_uint64(count), C.byref(bad))
+    return int(n), int(bad.value)
+
+
+def expf_device_mismatches(first_bits, count):
+    """The same count for gso_expf_device, the operation sequence the HIP kernels use (one binary64 operation fewer)."""
+    bad = C.c_uint32(0)
+    n = lib().gso_expf_device_mismatches(C.c_uint32(first_bits), C.c_uint64(count), C.byref(bad))
     return int(n), int(bad.value)
 
 

@@ -26,6 +26,17 @@ def test_equal_to_libm_on_every_nonpositive_binary32(oracle):
     assert bad == 0, f"{bad} mismatches against libm expf, first at bits {first:#x}"
 
 
+def test_the_kernels_operation_sequence_equals_libm_too(oracle):
+    """The HIP blend evaluates the same cubic times the same table value in four binary64 operations instead of glibc's
+    five (gs_expf_libm in gs_kernels.hip; gso_expf_device restates exactly that sequence).  IEEE binary64 arithmetic
+    gives the same bits on the host as on the device, so its equality with libm on every input the blend can ask for is
+    decided here, exhaustively -- and re-checked end to end by the GPU tests, where the frame must equal the reference
+    text's bit for bit."""
+    lo, hi = _bits(-0.0), _bits(float("-inf"))
+    bad, first = oracle.expf_device_mismatches(lo, hi - lo + 1)
+    assert bad == 0, f"{bad} mismatches against libm expf, first at bits {first:#x}"
+
+
 def test_spot_values_and_table(oracle):
     assert oracle.expf_libm(np.float32(0.0)) == 1.0 and oracle.expf_libm(np.float32(-0.0)) == 1.0
     assert oracle.expf_libm(np.float32(-1000.0)) == 0.0 and oracle.expf_libm(np.float32(-np.inf)) == 0.0
