@@ -574,9 +574,9 @@ struct gs_renderer {
 
     gs_frame_stats last{};  // stats of the most recently retired frame
 
-    // How a frame's per-tile lists get their depth order.  level 0 .. 3: bin-local -- the
-    // workgroup that builds a bin's lists orders its candidates in LDS first (up to 4096 / 8192 / 12288 / 16384 per bin; 6
-    // kernels per frame); level 4: global -- the V visible Gaussians are ordered first (12 more kernels; any bin size).
+    // How a frame's per-tile lists get their depth order.  level 0 .. 4: bin-local -- the
+    // workgroup that builds a bin's lists orders its candidates in LDS first (up to 4096 / 8192 / 12288 / 16384 per bin, or,
+    // level 4, up to 65535 in depth slabs of <= 12288; 6 kernels per frame); level 5: global -- the V visible Gaussians are ordered first (12 more kernels; any bin size).
     // sort_mode 0 = automatic: start at level 0; a bin that does not fit re-runs the frame at the level its size asks
     // for; after 32 frames that would have fitted the level below, go back down.
     int sort_mode = 0;           // 0 auto, 1 global depth order, 2 bin-local (forced: a bin beyond 16384 is an error)
@@ -940,9 +940,9 @@ struct gs_renderer {
             if (bin_too_big) {  // a bin outgrew the in-LDS order of this level: one level up from here on
                 int wanted = failed_level + 1;
                 while (wanted < kGlobalLevel && fullest > level_limit(wanted)) ++wanted;
-                if (wanted >= kGlobalLevel && can_refine(sl.u)) {  // smaller bins before giving up the bin-local path
+                if (wanted >= gs::kBinSlabLevel && can_refine(sl.u)) {  // smaller bins before slabs or the global path
                     refined = true;
-                    wanted = kGlobalLevel - 1;
+                    wanted = gs::kBinSlabLevel - 1;
                 } else {
                     if (sort_mode == 2 && wanted >= kGlobalLevel)
                         throw Error(GS_ERR_OVERFLOW, "a bin holds more candidates than the bin-local sort can order");
@@ -977,7 +977,7 @@ struct gs_renderer {
             if (sl.h_counters->max_bin <= level_limit(0) / 2) {  // four times the tiles per bin should still fit level 2
                 if (++frames_since_fallback >= 32) {
                     refined = false;
-                    level = kGlobalLevel - 1;
+                    level = gs::kBinSlabLevel - 1;
                     frames_since_fallback = 0;
                 }
             } else {

@@ -68,9 +68,11 @@ struct FrameParams {
     Counters* host_counters;
 };
 
-// candidates per bin that k_bin_fast orders in LDS at depth-order level 0 .. 3 (8 bytes of LDS each); level 4 = the global path
-constexpr int kBinSortLevels = 4;
-constexpr uint32_t kBinSortLimit[kBinSortLevels] = {4096, 8192, 12288, 16384};
+// candidates per bin that k_bin_fast orders in LDS at depth-order level 0 .. 3 (8 bytes of LDS each); level 4: k_bin_slabs,
+// bins of up to 65535 taken in depth slabs of <= 12288; level 5 = the global path
+constexpr int kBinSortLevels = 5;
+constexpr int kBinSlabLevel = 4;
+constexpr uint32_t kBinSortLimit[kBinSortLevels] = {4096, 8192, 12288, 16384, 65535};
 constexpr int kBinSortMax = 16384;
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s);
@@ -132,8 +134,8 @@ void launch_bin_level1_count(const BinLaunch& b, hipStream_t s);    // k_l1_hist
 // any_order: the candidates of a bin may land in any order inside each block's run (the bin-local path with bins of
 // <= 8 x 8 tiles orders them by (depth, id) anyway); otherwise item order is kept
 void launch_bin_level1_scatter(const BinLaunch& b, bool any_order, hipStream_t s);  // k_l1_scatter / k_l1_scatter_any_order
-// level 0 .. 3: the bin's candidates are ordered by (depth bits, id) in LDS, up to kBinSortLimit[level] per bin;
-// level 4: no ordering (the candidates arrive in depth order: global path), any bin size
+// level 0 .. 4: the bin's candidates are ordered by (depth bits, id) in LDS, up to kBinSortLimit[level] per bin (level 4 in
+// several slabs); level 5: no ordering (the candidates arrive in depth order: global path), any bin size
 void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s);  // k_bin_build
 
 // render.comp counterpart.

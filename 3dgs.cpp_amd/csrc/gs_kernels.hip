@@ -1614,7 +1614,12 @@ struct FastLayout {
     static constexpr int WORDS = 2 * MAXC + TAIL;
 };
 
-template <int ROUNDS>
+// SLABS: a bin of more than MAXC candidates (up to 65535) is taken in several rounds over the same LDS: its depth range is cut
+// into slabs of buckets holding <= MAXC candidates each (one pass for the depth range, one for the bucket histogram and the
+// per-tile totals -- which give the bin its list segment and the tile ranges up front --), and slab after slab the bin's
+// records are streamed again, the slab's members compacted into LDS, ordered, and appended to the tiles' lists behind what
+// the slabs in front of them wrote.  The slabs are depth-ordered and each is (depth, id)-ordered inside: so is the whole.
+template <int ROUNDS, bool SLABS = false>
 __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     using L = FastLayout<ROUNDS>;
     constexpr int THREADS = L::THREADS, NW = L::NW, MAXC = L::MAXC;
@@ -1633,14 +1638,20 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     uint32_t (*const s_seg)[64] = reinterpret_cast<uint32_t(*)[64]>(t_cnt + 128);                // [16][64]
     __shared__ uint32_t scratch[NW], scratch_hi[NW];
     __shared__ uint32_t s_seg0, s_flag;
-    constexpr uint32_t kSlotMask = 0x3FFFu;  // MAXC <= 16384
+    constexpr int kSlotBits = SLABS ? 16 : 14;  // a candidate's slot in the bin's record run: < MAXC <= 16384, or < 65536
+    constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1u;
+    constexpr uint32_t kMaxInBin = SLABS ? 65535u : (uint32_t)MAXC;
+    constexpr int kMaxSlabs = 12;
+    __shared__ uint32_t g_cur[SLABS ? 64 : 1], t_tot[SLABS ? 64 : 1];  // list cursors across the slabs; per-tile totals
+    __shared__ uint32_t slab_first[SLABS ? kMaxSlabs + 1 : 1];         // first bucket of each slab
+    __shared__ uint32_t s_fill;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     // one workgroup per ON-SCREEN bin (the grid is bins_x * bins_y: with the padding of the bin grid in it, workgroups
     // that exit at once upset the dispatcher's placement and a few CUs end up with three of the real ones)
     const uint32_t bin = ((blockIdx.x / a.g.bins_x) << a.g.grid_shift) | (blockIdx.x % a.g.bins_x);
     BUILD_T(0);
-    uint32_t c, off;
+    uint32_t c_total, off;
     {   // this bin's count and offset (the padded grid has <= 1024 = THREADS bins)
         const uint32_t nb = 1u << (2 * a.g.grid_shift);
         const uint32_t v = (uint32_t)tid < nb ? a.bin_count[tid] : 0u;
@@ -1650,25 +1661,28 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         // block-uniform by construction; telling the compiler so keeps everything derived from them (loop bounds, the
         // record buffer's descriptor) in scalar registers -- a descriptor it believes divergent is "waterfalled": every
         // load wrapped in a readfirstlane loop with a full s_waitcnt, i.e. serialised
-        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)tm);
+        c_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)tm);
         off = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
     }
-    if ((uint64_t)off + c > a.capacity) c = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
-    if (c > (uint32_t)MAXC) {
+    if ((uint64_t)off + c_total > a.capacity) c_total = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
+    if (c_total > kMaxInBin) {
         if (tid == 0) atomicOr(&a.counters->overflow, 2u);
-        c = 0;
+        c_total = 0;
     }
     if (tid == 0) s_flag = 0;
     BUILD_T(1);
-    const int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= ROUNDS
+    const bool multi = SLABS && c_total > (uint32_t)MAXC;  // block-uniform
+    // c: the candidates in LDS (the whole bin, or the current slab of it); rounds / wbase follow it
+    uint32_t c = multi ? 0u : c_total;
+    int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= ROUNDS
     // this bin's run of 12-byte records {key, id, box16} as a raw buffer: 32-bit offsets (one address register per load instead
     // of two) and the hardware's bounds check in place of branches (reads past the run return 0)
     typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
     uint32_t* const recs_ptr = a.cand + (size_t)kCandWords * off;
-#define recs uniform_rsrc(recs_ptr, c * 12u)  /* rebuilt from scalars at every use: see uniform_rsrc */
+#define recs uniform_rsrc(recs_ptr, c_total * 12u)  /* rebuilt from scalars at every use: see uniform_rsrc */
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
-    const uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
+    uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
     // One stable LSD pass over (s_key, s_pay) in place: digit = `db` (<= 9) bits of (s_key - sub) at `shift`; the pass
     // writes s_key - sub back (the first pass of a sort normalises the keys to the bin's smallest, the others pass sub = 0).
     auto radix_pass = [&](int shift, int db, uint32_t sub) {
@@ -1749,17 +1763,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         __syncthreads();
     };
     // smallest key and the span of the keys in LDS (block-uniform, scalar)
-    auto key_range = [&](uint32_t& kmin, uint32_t& span) {
-        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const uint32_t e = r * THREADS + tid;
-            if (r < rounds && e < c) {
-                const uint32_t k = s_key[e];
-                lo = min(lo, k);
-                hi = max(hi, k);
-            }
-        }
+    auto block_minmax = [&](uint32_t lo, uint32_t hi, uint32_t& kmin, uint32_t& span) {
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) {
             lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, WAVE));
@@ -1778,6 +1782,19 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         }
         kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
         span = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi) - kmin;
+    };
+    auto key_range = [&](uint32_t& kmin, uint32_t& span) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = r * THREADS + tid;
+            if (r < rounds && e < c) {
+                const uint32_t k = s_key[e];
+                lo = min(lo, k);
+                hi = max(hi, k);
+            }
+        }
+        block_minmax(lo, hi, kmin, span);
     };
     // Order (s_key, s_pay) by s_key with stable LSD passes: the keys are normalised to the smallest of them, which leaves
     // `bits` significant bits (25 or so for the depths of one bin of a frame: three passes of nine bits)
@@ -1889,6 +1906,161 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         }
         return sort_by_key_lsd(kmin, span);
     };
+    const int S = 1 << a.g.bin_shift;
+    // the bin's list segment and its tiles' ranges, from the per-tile instance counts (lane t < 64: tile t of the bin)
+    auto place_lists = [&](uint32_t v, uint32_t* cursors) {
+        uint32_t d_bin;
+        const uint32_t excl = block_excl_scan<THREADS>(v, scratch, &d_bin);
+        if (tid == 0) {
+            const uint32_t seg = d_bin ? atomicAdd(&a.counters->instances, d_bin) : 0u;
+            s_seg0 = seg;
+            if ((uint64_t)seg + d_bin > a.capacity) atomicOr(&a.counters->overflow, 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t ox = (bin & ((1u << a.g.grid_shift) - 1u)) << a.g.bin_shift, oy = (bin >> a.g.grid_shift) << a.g.bin_shift;
+            const uint32_t lx = (uint32_t)tid & (uint32_t)(S - 1), ly = (uint32_t)tid >> a.g.bin_shift;
+            const uint32_t x = ox + lx, y = oy + ly;
+            // saturating: an overflowing frame is re-run, but its ranges must stay inside the list
+            const uint64_t start64 = (uint64_t)s_seg0 + excl;
+            const uint32_t start = start64 > a.capacity ? a.capacity : (uint32_t)start64;
+            const uint32_t end = start64 + v > a.capacity ? a.capacity : (uint32_t)(start64 + v);
+            if (ly < (uint32_t)S && x < a.g.tiles_x && y < a.g.tiles_y) {
+                // absent tiles stay (0, 0) like the reference's zero-filled tileBoundaryBuffer
+                a.ranges[2 * (y * a.g.tiles_x + x)] = v ? start : 0u;
+                a.ranges[2 * (y * a.g.tiles_x + x) + 1] = v ? end : 0u;
+            }
+            cursors[tid] = start;
+        }
+    };
+    // ---- a bin beyond MAXC: its depth range, the bucket histogram, the per-tile totals, the slabs
+    uint32_t n_slabs = 1, g_kmin = 0;
+    int g_sh = 0;
+    if (multi) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (uint32_t base = 0; base < c_total; base += 8 * THREADS) {  // pass 0: the keys' range (eight loads in flight)
+            uint32_t k[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) k[r] = __builtin_amdgcn_raw_buffer_load_b32(recs, (base + r * THREADS + tid) * 12u, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (base + r * THREADS + tid < c_total) {
+                    lo = min(lo, k[r]);
+                    hi = max(hi, k[r]);
+                }
+        }
+        uint32_t span;
+        block_minmax(lo, hi, g_kmin, span);
+        const int bits = span ? 32 - __builtin_clz(span) : 0;
+        g_sh = bits > 12 ? bits - 12 : 0;
+        for (uint32_t k = tid; k < kMsdBuckets / 2; k += THREADS) m_cnt[k] = 0;
+        if (tid < 64) t_tot[tid] = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < c_total; base += 8 * THREADS) {  // pass 1: buckets and per-tile totals
+            uint32_t k[8], bx[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const u32x3 rec = __builtin_amdgcn_raw_buffer_load_b96(recs, (base + r * THREADS + tid) * 12u, 0, 0);
+                k[r] = rec.x;
+                bx[r] = rec.z;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (base + r * THREADS + tid < c_total) {
+                    const uint32_t bk = (k[r] - g_kmin) >> g_sh;
+                    atomicAdd(&m_cnt[bk >> 1], 1u << (16u * (bk & 1u)));  // <= 65535 per bucket: no carry
+                    const uint32_t pb = bx[r], lx0 = pb & 15u, ly0 = (pb >> 4) & 15u, lx1 = (pb >> 8) & 15u, ly1 = (pb >> 12) & 15u;
+                    for (uint32_t y = ly0; y <= ly1; ++y)
+                        for (uint32_t x = lx0; x <= lx1; ++x) atomicAdd(&t_tot[(y << a.g.bin_shift) + x], 1u);
+                }
+        }
+        __syncthreads();
+        {   // exclusive prefix over the buckets (thread t: buckets 4 t .. 4 t + 3), kept as u16 (the bin holds < 65536)
+            const uint2 w2 = reinterpret_cast<const uint2*>(m_cnt)[tid];
+            const uint32_t v0 = w2.x & 0xFFFFu, v1 = w2.x >> 16, v2 = w2.y & 0xFFFFu, v3 = w2.y >> 16;
+            uint32_t all;
+            const uint32_t excl = block_excl_scan<THREADS>(v0 + v1 + v2 + v3, scratch, &all);
+            if (max(max(v0, v1), max(v2, v3)) > (uint32_t)MAXC) s_flag = 3;  // one bucket beyond a slab: the global path
+            ushort4 st;
+            st.x = (unsigned short)excl;
+            st.y = (unsigned short)(excl + v0);
+            st.z = (unsigned short)(excl + v0 + v1);
+            st.w = (unsigned short)(excl + v0 + v1 + v2);
+            reinterpret_cast<ushort4*>(m_start)[tid] = st;
+            if (tid == 0) {
+                slab_first[0] = 0;
+                s_fill = 1;  // slabs so far
+            }
+        }
+        __syncthreads();
+        // slab k + 1 starts at the first bucket that no longer fits behind slab k's first (every thread looks at its four)
+        for (int k = 0; k < kMaxSlabs; ++k) {
+            const uint32_t base = m_start[slab_first[k]];
+            if (c_total - base <= (uint32_t)MAXC) break;  // block-uniform: the rest fits
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t bk = 4u * tid + j;
+                const uint32_t p0 = m_start[bk], p1 = bk + 1 < kMsdBuckets ? (uint32_t)m_start[bk + 1] : c_total;
+                if (p0 - base <= (uint32_t)MAXC && p1 - base > (uint32_t)MAXC && bk > slab_first[k]) {
+                    slab_first[k + 1] = bk;
+                    s_fill = k + 2;
+                }
+            }
+            __syncthreads();
+            if (s_fill != (uint32_t)k + 2) {  // (cannot happen while no bucket exceeds MAXC; keeps the loop finite)
+                if (tid == 0) s_flag = 3;
+                break;
+            }
+        }
+        __syncthreads();
+        n_slabs = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fill);
+        if (tid == 0) slab_first[n_slabs] = kMsdBuckets;
+        const uint32_t remaining = c_total - m_start[slab_first[n_slabs - 1]];
+        if (__builtin_amdgcn_readfirstlane((int)s_flag) == 3 || remaining > (uint32_t)MAXC) {
+            if (tid == 0) atomicOr(&a.counters->overflow, 2u);
+            n_slabs = 0;
+        }
+        __syncthreads();
+        if (tid == 0) s_flag = 0;
+        place_lists(tid < 64 ? t_tot[tid] : 0u, g_cur);
+        __syncthreads();
+    }
+    for (uint32_t slab = 0; slab < n_slabs; ++slab) {
+    if (multi) {  // ---- this slab's members, compacted into LDS (any order: they are ordered next)
+        const uint32_t b_lo = slab_first[slab], b_hi = slab_first[slab + 1];
+        __syncthreads();  // the previous slab is done with LDS
+        if (tid == 0) s_fill = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < c_total; base += 8 * THREADS) {
+            uint32_t k[8], bx[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const u32x3 rec = __builtin_amdgcn_raw_buffer_load_b96(recs, (base + r * THREADS + tid) * 12u, 0, 0);
+                k[r] = rec.x;
+                bx[r] = rec.z;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t e = base + r * THREADS + tid;
+                const uint32_t bk = (k[r] - g_kmin) >> g_sh;
+                const bool mine = e < c_total && bk >= b_lo && bk < b_hi;
+                const uint64_t mm = __builtin_amdgcn_ballot_w64(mine);  // one atomic per wave and round
+                if (mm != 0) {
+                    uint32_t at = 0;
+                    if (lane == __ffsll((unsigned long long)mm) - 1) at = atomicAdd(&s_fill, (uint32_t)__popcll(mm));
+                    at = (uint32_t)__builtin_amdgcn_readlane((int)at, __ffsll((unsigned long long)mm) - 1) + (uint32_t)__popcll(mm & lt_mask);
+                    if (mine && at < (uint32_t)MAXC) {
+                        s_key[at] = k[r];
+                        s_pay[at] = e | (bx[r] << kSlotBits);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        c = min((uint32_t)__builtin_amdgcn_readfirstlane((int)s_fill), (uint32_t)MAXC);
+        rounds = (int)((c + THREADS - 1) / THREADS);
+        wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
+    }
     // attempt 0: the records as level 1 left them (any order inside a block's run).  attempt 1 (only after a run of more
     // than 64 equal depths, i.e. a degenerate scene): the records rewritten in id order, so that the stable passes alone
     // leave equal depths in id order
@@ -1898,6 +2070,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         uint32_t tid12 = (uint32_t)tid * 12u;
         asm volatile("" : "+v"(tid12));  // opaque: or the sixteen offsets are hoisted out of the attempt loop, kept, and spilled
         constexpr int HR = ROUNDS <= 8 ? ROUNDS : ROUNDS / 2;  // 4, 8, 6, 8
+        if (!multi)
 #pragma unroll
         for (int h = 0; h < ROUNDS; h += HR) {
             uint32_t k[HR], b[HR];
@@ -1917,7 +2090,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
                 const uint32_t e = (h + r) * THREADS + tid;
                 if (h + r < rounds && e < c) {
                     s_key[e] = k[r];
-                    s_pay[e] = e | (b[r] << 14);
+                    s_pay[e] = e | (b[r] << kSlotBits);
                 }
             }
         }
@@ -1959,6 +2132,12 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         }
         __syncthreads();
         if (attempt == 0) BUILD_T(9);
+        if (multi && redo) {  // a run of > 64 equal depths inside a slab: not handled here -- the global path takes the frame
+            if (tid == 0) atomicOr(&a.counters->overflow, 2u);
+            __syncthreads();
+            if (tid == 0) s_flag = 0;
+            break;
+        }
         if (!redo) {
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
@@ -1993,7 +2172,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
                 const uint32_t pw = s_pay[e];
                 nk[r] = __builtin_amdgcn_raw_buffer_load_b32(recs, (pw & kSlotMask) * 12u, 0, 0);
                 ni[r] = s_id[e] + id_base;
-                nb[r] = pw >> 14;
+                nb[r] = pw >> kSlotBits;
             }
         }
         __syncthreads();  // (workgroup-scope fence included) every record has been read before any is overwritten
@@ -2013,13 +2192,12 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     BUILD_T(3);
     // ---- the candidates' tile boxes inside the bin (they rode along in the payload), and the (chunk, tile) counts
     const uint32_t nch = (c + WAVE - 1) / WAVE;
-    const int S = 1 << a.g.bin_shift;
     {
         uint32_t pb16[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t e = r * THREADS + tid;
-            pb16[r] = e < c ? s_pay[e] >> 14 : 0u;
+            pb16[r] = e < c ? s_pay[e] >> kSlotBits : 0u;
         }
         __syncthreads();  // the payloads are dead from here on: their area becomes boxes + chunk table
         for (uint32_t k = tid; k < (uint32_t)MAXC / 2; k += THREADS) smem[MAXC / 2 + k] = 0;  // the table
@@ -2086,32 +2264,12 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     }
     __syncthreads();
     BUILD_T(5);
-    // ---- tile ranges: a segment of the list buffer for the bin (tiles consecutive inside it)
-    {
-        const uint32_t v = tid < 64 ? t_cnt[tid] : 0u;
-        uint32_t d_bin;
-        const uint32_t excl = block_excl_scan<THREADS>(v, scratch, &d_bin);
-        if (tid == 0) {
-            const uint32_t seg = d_bin ? atomicAdd(&a.counters->instances, d_bin) : 0u;
-            s_seg0 = seg;
-            if ((uint64_t)seg + d_bin > a.capacity) atomicOr(&a.counters->overflow, 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const uint32_t ox = (bin & ((1u << a.g.grid_shift) - 1u)) << a.g.bin_shift, oy = (bin >> a.g.grid_shift) << a.g.bin_shift;
-            const uint32_t lx = (uint32_t)tid & (uint32_t)(S - 1), ly = (uint32_t)tid >> a.g.bin_shift;
-            const uint32_t x = ox + lx, y = oy + ly;
-            // saturating: an overflowing frame is re-run, but its ranges must stay inside the list
-            const uint64_t start64 = (uint64_t)s_seg0 + excl;
-            const uint32_t start = start64 > a.capacity ? a.capacity : (uint32_t)start64;
-            const uint32_t end = start64 + v > a.capacity ? a.capacity : (uint32_t)(start64 + v);
-            if (ly < (uint32_t)S && x < a.g.tiles_x && y < a.g.tiles_y) {
-                // absent tiles stay (0, 0) like the reference's zero-filled tileBoundaryBuffer
-                a.ranges[2 * (y * a.g.tiles_x + x)] = v ? start : 0u;
-                a.ranges[2 * (y * a.g.tiles_x + x) + 1] = v ? end : 0u;
-            }
-            t_cur[tid] = start;
-        }
+    // ---- tile ranges: a segment of the list buffer for the bin (tiles consecutive inside it) -- or, for a slab of a bin
+    // that was placed up front, where the slabs before this one left each tile's list
+    if (!multi) {
+        place_lists(tid < 64 ? t_cnt[tid] : 0u, t_cur);
+    } else if (tid < 64) {
+        t_cur[tid] = g_cur[tid];
     }
     __syncthreads();
     BUILD_T(6);
@@ -2146,6 +2304,8 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             walk_column(wave_transpose64(m[0], lane), base, out, s_id + ch * WAVE);
         }
     }
+    if (multi && tid < 64) g_cur[tid] += t_cnt[tid];  // (t_cnt: this slab's per-tile counts; the next slab starts with a barrier)
+    }  // slabs
     BUILD_T(7);
 }
 // 8 waves per SIMD for the two smaller sizes, i.e. two workgroups per CU: needs <= 64 VGPRs and <= 80 SGPRs (a SIMD has
@@ -2155,6 +2315,8 @@ template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<4>(BuildArgs a
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<8>(BuildArgs a) { bin_fast_body<8>(a); }
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<12>(BuildArgs a) { bin_fast_body<12>(a); }
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<16>(BuildArgs a) { bin_fast_body<16>(a); }
+// bins of up to 65535 candidates, taken in slabs of <= 12288 (depth-order level 4)
+__global__ __launch_bounds__(1024, 4) void k_bin_slabs(BuildArgs a) { bin_fast_body<12, true>(a); }
 
 static L1Args l1_args(const BinLaunch& b) {
     L1Args a;
@@ -2229,6 +2391,9 @@ hipError_t bin_prepare_device() {  // once per device (gs_renderer::init)
     if (e == hipSuccess) e = fast_prepare<8>();
     if (e == hipSuccess) e = fast_prepare<12>();
     if (e == hipSuccess) e = fast_prepare<16>();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_slabs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FastLayout<12>::WORDS * sizeof(uint32_t)));
     return e;
 }
 
@@ -2257,7 +2422,8 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
         if (level == 0) hipLaunchKernelGGL(k_bin_fast<4>, dim3(bins), dim3(1024), FastLayout<4>::WORDS * sizeof(uint32_t), s, a);
         else if (level == 1) hipLaunchKernelGGL(k_bin_fast<8>, dim3(bins), dim3(1024), FastLayout<8>::WORDS * sizeof(uint32_t), s, a);
         else if (level == 2) hipLaunchKernelGGL(k_bin_fast<12>, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
-        else hipLaunchKernelGGL(k_bin_fast<16>, dim3(bins), dim3(1024), FastLayout<16>::WORDS * sizeof(uint32_t), s, a);
+        else if (level == 3) hipLaunchKernelGGL(k_bin_fast<16>, dim3(bins), dim3(1024), FastLayout<16>::WORDS * sizeof(uint32_t), s, a);
+        else hipLaunchKernelGGL(k_bin_slabs, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
     } else if (b.bin_shift <= 3) {
         launch_build<1>(a, sort, bins, s);
     } else if (b.bin_shift == 4) {

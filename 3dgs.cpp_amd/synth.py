@@ -72,7 +72,12 @@ def _trained_like(rec, n, seed, idx, p):
     for k, (lohi, g) in enumerate(((p["x"], gx), (p["y"], gy), (p["z"], gz))):
         c = lerp(lohi, _uniform(cseed, cid, k))
         v = np.where(background, lerp(lohi, _uniform(seed, idx, k)), c + sig * g * (1.0 if k < 2 else 1.6))
-        rec[:, k] = np.clip(v, lohi[0] - 1.0, -0.5 if k == 2 else lohi[1] + 1.0)
+        # keep the blobs' tails inside the box by folding them back at its walls (clipping would pile thousands of
+        # Gaussians onto one exact coordinate -- for z: one exact depth, a degenerate key run no trained scene has)
+        lo_w, hi_w = lohi[0] - 1.0, (-0.5 if k == 2 else lohi[1] + 1.0)
+        v = np.where(v < lo_w, 2.0 * lo_w - v, v)
+        v = np.where(v > hi_w, 2.0 * hi_w - v, v)
+        rec[:, k] = np.clip(v, lo_w, hi_w)
     s0, s1 = _normal_pair(seed, idx, 3)
     s2, _ = _normal_pair(seed, idx, 5)
     stretch_axis = (np.floor(_uniform(seed, idx, 76) * 3)).astype(np.int64)

@@ -76,7 +76,7 @@ typedef struct {
     uint32_t max_bin_entries; /* candidates in the fullest bin */
     uint32_t sort_path;       /* depth-order path the frame took: 1 = global, 2 = bin-local (gs_set_sort_path) */
     uint32_t bin_tiles;       /* edge of the frame's bins in tiles (4, 8, 16 or 32) */
-    uint32_t sort_level;      /* 0 .. 3: in-LDS order of up to 4096 / 8192 / 12288 / 16384 candidates per bin; 4: global path */
+    uint32_t sort_level;      /* 0 .. 3: in-LDS order of up to 4096 / 8192 / 12288 / 16384 candidates per bin; 4: up to 65535 in depth slabs; 5: global path */
     uint32_t pad_;
 } gs_frame_stats;
 

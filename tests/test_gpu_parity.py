@@ -149,6 +149,31 @@ def test_degenerate_keys(pkg, oracle, gpu):
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
 
 
+@pytest.mark.parametrize("layout", ["two_walls", "thin_slab", "wall_and_fog", "short_ties"])
+def test_depth_distributions_against_the_bucket_order(pkg, oracle, gpu, layout):
+    """k_bin_fast orders a bin by cutting its depth range into 4096 buckets and ranking inside the buckets; when a bucket is
+    crowded it falls back to stable passes.  Depth distributions chosen to hit every branch: two thin walls far apart (two
+    buckets hold everything: the fallback), a slab thinner than 4096 key values (the bucket index is the key offset itself),
+    a wall inside a fog (one crowded bucket among sparse ones), and many short runs of exactly equal depths (the tie step
+    after either order).  Lists, ranges and image must equal the oracle's, i.e. the reference's stable sort."""
+    n = 12000
+    rec = pkg.synth.synth_records(n, seed=77, kind="A")
+    rng = np.random.default_rng(77)
+    if layout == "two_walls":
+        rec[:, 2] = np.where(rng.random(n) < 0.5, -2.5, -9.0) + rng.uniform(-2e-4, 2e-4, n)
+    elif layout == "thin_slab":
+        base = np.float32(-4.0).view(np.uint32)
+        rec[:, 2] = (base + rng.integers(0, 900, n).astype(np.uint32)).view(np.float32)  # 900 adjacent binary32 values
+    elif layout == "wall_and_fog":
+        rec[: n // 2, 2] = -5.0 + rng.uniform(-1e-4, 1e-4, n // 2)
+    else:
+        rec[:, 2] = -np.round(rng.uniform(2.2, 9.0, n) * 400) / 400  # ~2700 distinct depths: runs of 4-5 equal keys
+    rec[:, 0:2] *= 0.6  # denser bins
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, 512, 288)
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+
+
 def test_one_dense_bin(pkg, oracle, gpu):
     """Thousands of splats inside one 128x128-pixel bin: long chunk lists in a single bin, empty bins elsewhere."""
     rec = pkg.synth.synth_records(20000, seed=9, kind="A")
@@ -356,9 +381,10 @@ def _dense_bin_records(pkg, n=20000):
 
 
 def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
-    """gs_set_sort_path: the bin-local path (one in-LDS sort per bin) and the global depth order build the same
-    lists; a bin beyond 16384 candidates is an error when the bin-local path is forced and a transparent re-run on the
-    global path in automatic mode; once the bins fit again for 32 frames the automatic mode returns."""
+    """gs_set_sort_path: the bin-local path (one in-LDS order per bin) and the global depth order build the same
+    lists.  A bin beyond 16384 candidates is taken in depth slabs (level 4, still bin-local) up to 65535; beyond that it is
+    an error when the bin-local path is forced and a transparent re-run on the global path in automatic mode; once the
+    bins fit again for 32 frames the automatic mode steps back."""
     monkeypatch.delenv("GS_SORT_PATH", raising=False)
     w, h = 640, 360
     # (1) a scene whose bins all fit: both forced paths, stage by stage
@@ -376,8 +402,24 @@ def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
         np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
         rend.close()
     scene.close()
-    # (2) 20 000 splats in one bin
-    rec = _dense_bin_records(pkg)
+    # (2) 20 000 and 40 000 splats in one bin: depth slabs, forced or automatic
+    for n in (20000, 40000):
+        rec = _dense_bin_records(pkg, n)
+        verts, u_ref, ref = oracle_frame(oracle, rec, w, h)
+        scene = pkg.Scene.from_records(rec)
+        for mode in (2, 0):
+            rend = pkg.Renderer(scene)
+            rend.set_sort_path(mode)
+            img, _ = rend.render_host(u)
+            st = rend.stats()
+            assert st.sort_path == 2 and st.sort_level == 4 and st.retries >= 1 and 16384 < st.max_bin_entries <= 65535, \
+                (st.sort_path, st.sort_level, st.retries, st.max_bin_entries)
+            compare_stages(pkg, rend, u, ref)
+            np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+            rend.close()
+        scene.close()
+    # (3) 70 000 splats in one bin: beyond the slabs
+    rec = _dense_bin_records(pkg, 70000)
     verts, u_ref, ref = oracle_frame(oracle, rec, w, h)
     scene = pkg.Scene.from_records(rec)
     rend = pkg.Renderer(scene)
@@ -389,10 +431,10 @@ def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
     rend = pkg.Renderer(scene)  # automatic
     img, _ = rend.render_host(u)
     st = rend.stats()
-    assert st.sort_path == 1 and st.retries >= 1 and st.max_bin_entries > 16384
+    assert st.sort_path == 1 and st.retries >= 1 and st.max_bin_entries > 65535
     compare_stages(pkg, rend, u, ref)
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
-    # (3) the camera turns away from the dense bin: after 32 fitting frames the bin-local path is back
+    # (4) the camera turns away from the dense bin: after 32 fitting frames the bin-local path is back
     away = pkg.make_camera(rotation=(0.0, 0.0, 1.0, 0.0))  # looking down +z: nothing in view
     ua = pkg.camera_uniforms(away, w, h)
     for _ in range(40):
@@ -403,6 +445,32 @@ def test_sort_paths_agree_and_fall_back(pkg, oracle, gpu, monkeypatch):
     np.testing.assert_array_equal(img2.view(np.uint32), ref["image"].view(np.uint32))
     rend.close()
     scene.close()
+
+
+def test_depth_slabs_with_concentrated_depths(pkg, oracle, gpu, monkeypatch):
+    """The slab cut is made on depth buckets: a dense bin whose candidates crowd into ONE bucket (a wall seen face on,
+    30 000 splats within 1e-4 of one depth) cannot be cut and goes to the global path; the same bin with two such walls
+    plus a spread-out rest is cut between them.  Both must give the oracle's lists and pixels."""
+    monkeypatch.setenv("GS_SORT_PATH", "0")
+    w, h = 640, 360
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    rng = np.random.default_rng(5)
+    for name, depth in [("one wall", lambda n: -4.0 + rng.uniform(-5e-5, 5e-5, n)),
+                        ("two walls and fog", lambda n: np.where(rng.random(n) < 0.3, -3.0, np.where(rng.random(n) < 0.5, -6.0, rng.uniform(-9, -2.2, n)))
+                                                        + rng.uniform(-5e-5, 5e-5, n))]:
+        rec = _dense_bin_records(pkg, 30000)
+        rec[:, 2] = depth(len(rec))
+        verts, u_ref, ref = oracle_frame(oracle, rec, w, h)
+        scene = pkg.Scene.from_records(rec)
+        rend = pkg.Renderer(scene)
+        img, _ = rend.render_host(u)
+        st = rend.stats()
+        print(f"{name}: path {st.sort_path} level {st.sort_level} fullest bin {st.max_bin_entries} retries {st.retries}")
+        assert st.max_bin_entries > 16384
+        compare_stages(pkg, rend, u, ref)
+        np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+        rend.close()
+        scene.close()
 
 
 def test_bin_local_sort_at_its_capacity(pkg, oracle, gpu, monkeypatch):
@@ -425,8 +493,8 @@ def test_bin_local_sort_at_its_capacity(pkg, oracle, gpu, monkeypatch):
 
 
 def test_many_path_fallbacks_do_not_exhaust_a_lifetime_budget(pkg, oracle, gpu, monkeypatch):
-    """A fly-through that enters and leaves a dense bin: every entry re-runs the frame on the global depth order
-    (one redo each), every exit returns to the bin-local path after 32 fitting frames.  More than 70 such round
+    """A fly-through that enters and leaves a dense bin: every entry re-runs the frame at the level the bin asks for (depth
+    slabs: one redo each), every exit steps back down after 32 fitting frames.  More than 70 such round
     trips must neither raise GS_ERR_OVERFLOW (the guard counts CONSECUTIVE re-runs of a frame) nor change a pixel."""
     monkeypatch.setenv("GS_SORT_PATH", "0")  # automatic path choice is what is under test
     rec = pkg.synth.synth_records(30000, seed=21, kind="A")
@@ -448,7 +516,7 @@ def test_many_path_fallbacks_do_not_exhaust_a_lifetime_budget(pkg, oracle, gpu, 
     rend.synchronize()
     st = rend.stats()
     assert st.retries >= 72, st.retries
-    assert st.sort_path == 1 and st.max_bin_entries > 16384
+    assert st.sort_path == 2 and st.sort_level == 4 and st.max_bin_entries > 16384  # 30 000 in one bin: depth slabs
     ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), w, h))
     np.testing.assert_array_equal(dev.download(target, (h, w, 4), np.float32), ref["image"])
     np.testing.assert_array_equal(rend.stage("sorted_gid"), ref["sorted_payload"])
