@@ -1671,7 +1671,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     }
     if (tid == 0) s_flag = 0;
     BUILD_T(1);
-    const bool multi = SLABS && c_total > (uint32_t)MAXC;  // block-uniform
+    const bool multi = SLABS ? c_total > (uint32_t)MAXC : false;  // block-uniform
     // c: the candidates in LDS (the whole bin, or the current slab of it); rounds / wbase follow it
     uint32_t c = multi ? 0u : c_total;
     int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= ROUNDS
@@ -1936,7 +1936,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // ---- a bin beyond MAXC: its depth range, the bucket histogram, the per-tile totals, the slabs
     uint32_t n_slabs = 1, g_kmin = 0;
     int g_sh = 0;
-    if (multi) {
+    if constexpr (SLABS) if (multi) {
         uint32_t lo = 0xFFFFFFFFu, hi = 0u;
         for (uint32_t base = 0; base < c_total; base += 8 * THREADS) {  // pass 0: the keys' range (eight loads in flight)
             uint32_t k[8];
@@ -2025,8 +2025,10 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         place_lists(tid < 64 ? t_tot[tid] : 0u, g_cur);
         __syncthreads();
     }
-    for (uint32_t slab = 0; slab < n_slabs; ++slab) {
-    if (multi) {  // ---- this slab's members, compacted into LDS (any order: they are ordered next)
+    // (a lambda, not a loop body: with a loop around it -- even one of a constant single trip -- the register allocator
+    // of hipcc 7.2 spills 45 instead of 19 registers in k_bin_fast<12>)
+    auto slab_body = [&](const uint32_t slab) {
+    if constexpr (SLABS) if (multi) {  // ---- this slab's members, compacted into LDS (any order: they are ordered next)
         const uint32_t b_lo = slab_first[slab], b_hi = slab_first[slab + 1];
         __syncthreads();  // the previous slab is done with LDS
         if (tid == 0) s_fill = 0;
@@ -2070,9 +2072,9 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         uint32_t tid12 = (uint32_t)tid * 12u;
         asm volatile("" : "+v"(tid12));  // opaque: or the sixteen offsets are hoisted out of the attempt loop, kept, and spilled
         constexpr int HR = ROUNDS <= 8 ? ROUNDS : ROUNDS / 2;  // 4, 8, 6, 8
-        if (!multi)
+        const int h_end = multi ? 0 : ROUNDS;  // (a slab's members are in LDS already)
 #pragma unroll
-        for (int h = 0; h < ROUNDS; h += HR) {
+        for (int h = 0; h < h_end; h += HR) {
             uint32_t k[HR], b[HR];
 #pragma unroll
             for (int r = 0; r < HR; ++r) {
@@ -2305,7 +2307,12 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         }
     }
     if (multi && tid < 64) g_cur[tid] += t_cnt[tid];  // (t_cnt: this slab's per-tile counts; the next slab starts with a barrier)
-    }  // slabs
+    };
+    if constexpr (SLABS) {
+        for (uint32_t slab = 0; slab < n_slabs; ++slab) slab_body(slab);
+    } else {
+        slab_body(0u);
+    }
     BUILD_T(7);
 }
 // 8 waves per SIMD for the two smaller sizes, i.e. two workgroups per CU: needs <= 64 VGPRs and <= 80 SGPRs (a SIMD has

@@ -444,7 +444,7 @@ def roofline(pkg, pass_name, wkey, mode, alg_bytes, ms_timed, ms_serial, ms_per_
                 one_in_flight={"ms": round(ms_serial, 4), "frac": round(r1 / VALU_PEAK, 4) if r1 else None,
                                "frac_of_sustained": round(r1 / VALU_SUSTAINED, 4) if r1 else None},
                 hbm=hbm,
-                note="wave_insts counts every VALU instruction as one issue slot; the default blend's ten binary64 operations per "
+                note="wave_insts counts every VALU instruction as one issue slot; the default blend's nine binary64 operations per "
                      "pair occupy two each (half rate), so the issue pipe is busier than frac says")
 
 

@@ -1,4 +1,4 @@
-"""The bench line's contract (task statement), checked on the committed round-2 line and on bench.py's
+"""The bench line's contract (task statement), checked on the committed round-3 line and on bench.py's
 own byte model -- no GPU needed."""
 import importlib.util
 import json
@@ -15,12 +15,13 @@ def _bench_module():
 
 
 def test_committed_bench_line_has_every_contract_field():
-    with open(os.path.join(ROOT, "profiles", "r02b_bench_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_default.json")) as f:
         b = json.load(f)
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         base = json.load(f)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timed"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timed", "parity",
+                "frames_per_s_strict", "frames_per_s_fast_blend", "frames_per_s_hw_exp"):
         assert key in b, key
     assert base["metric"].startswith(b["metric"])  # the headline clause of BASELINE.json's metric
     assert b["unit"] == "frames/s" and b["higher_is_better"] is True
@@ -30,12 +31,22 @@ def test_committed_bench_line_has_every_contract_field():
     assert abs(b["value"] - 1e3 / b["ms_per_step"]) / b["value"] < 1e-3  # whole-job frames / wall time of the median batch
     assert b["timed"]["batches"] >= 1 and b["timed"]["batch_ms"]["min"] <= b["timed"]["batch_ms"]["median"] <= b["timed"]["batch_ms"]["max"]
     r = b["roofline"]
-    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms", "one_in_flight"):
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_frame", "one_in_flight", "flops_view", "basis"):
         assert key in r, key
-    assert r["bound"] in ("valu", "hbm") and r["kernel"] == "k_blend"
+    assert r["bound"] in ("valu", "hbm") and r["kernel"].startswith("k_blend")
+    assert abs(r["ms_per_frame"] - b["ms_per_step"]) < 1e-3  # frac is computed on the frame time, not on an overlapped span
+    # the default is the reference-exact blend, and the line says how far each mode is from the reference text
+    assert "reference-exact" in b["config"]["blend"] and b["frames_per_s_strict"] == b["value"]
+    p = b["parity"]
+    assert p["default"]["bit_identical"] is True and p["default"]["max_abs_vs_reference_text"] == 0.0
+    assert p["fast"]["max_abs_vs_reference_text"] > 0 and "reference text" in p["against"]
+    assert b["frames_per_s_fast_blend"] > b["value"]
     if r["bound"] == "valu":  # counters of this very library: VALU issue against the spec rate, HBM view beside it
         assert r["peak"] == 1228.8 and r["unit"] == "G wave64-inst/s" and r["traffic"] > 0 and r["wave_insts"] > 1e8
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert abs(r["frac"] - r["wave_insts"] / (r["ms_per_frame"] * 1e-3) / 1228.8e9) < 1e-3   # by division from profiles/
+        fv = r["flops_view"]
+        assert abs(fv["frac"] - 22 * fv["walked_pairs"] / (r["ms_per_frame"] * 1e-3) / 157.3e12) < 1e-3
         assert r["hbm"]["peak"] == 8000.0 and r["hbm"]["unit"] == "GB/s" and abs(r["hbm"]["frac"] - r["hbm"]["achieved"] / 8000.0) < 1e-3
         assert 0 < r["frac"] < 1 and 0 < r["one_in_flight"]["frac"] < 1
     else:
