@@ -465,6 +465,7 @@ struct FrameBuffers {
     DevBuf<uint32_t> cand;                // [3 x capacity] bin-major candidates: 12-byte records {depth bits, id, box} on the bin-local path, plain ids otherwise
     DevBuf<uint32_t> sorted;              // [capacity + 4] per-tile lists, bin-major
     DevBuf<uint32_t> ranges;              // [T][2]
+    DevBuf<uint8_t> slabs;                // depth-slab descriptors (level 4; allocated on first use)
     DevBuf<gs::Counters> counters;
     // HIP-graph replay (gs_set_graph_mode): the frame's fixed-shape launches captured once per configuration
     DevBuf<gs::FrameParams> params;
@@ -748,10 +749,11 @@ struct gs_renderer {
         const BinGeometry geo = bin_geometry(tx, ty);
         const int lv = frame_level();
         const bool bin_local = lv < kGlobalLevel;
-        if (2 * nt > fb.ranges.n || (!bin_local && !fb.dkeys[0].p)) {
+        if (2 * nt > fb.ranges.n || (!bin_local && !fb.dkeys[0].p) || (lv == gs::kBinSlabLevel && !fb.slabs.p)) {
             drain();  // (re)allocation: wait for queued frames that still use the old buffers
             fb.ranges.ensure(2 * nt);
             if (!bin_local) fb.ensure_depth_order();
+            if (lv == gs::kBinSlabLevel && !fb.slabs.p) fb.slabs.alloc(static_cast<size_t>(gs::kSlabCapacity) * gs::kSlabDescBytes);
         }
         num_tiles = nt;
         ensure_tile_order(tx, ty);
@@ -816,6 +818,8 @@ struct gs_renderer {
                 b.sorted_gid = fb.sorted.p;
                 b.counters = cnt;
                 b.capacity = capacity;
+                b.slabs = fb.slabs.p;
+                b.slab_capacity = fb.slabs.p ? gs::kSlabCapacity : 0u;
                 b.tiles_x = tx;
                 b.tiles_y = ty;
                 b.bins_x = geo.bins_x;

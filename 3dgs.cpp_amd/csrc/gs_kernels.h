@@ -56,7 +56,7 @@ struct Counters {
     uint32_t overflow;   // bit 0: the capacity (candidates or lists) was exceeded; bit 1: a bin outgrew the in-LDS order of its level
     uint32_t bin_entries;  // E1: (bin, Gaussian) candidates of the level-1 binning
     uint32_t max_bin;    // candidates in the fullest bin
-    uint32_t pad;
+    uint32_t slabs;      // depth-slab descriptors written by k_bin_slabs for k_slab_work (level 4)
 };
 // What changes from one frame to the next.  Normally these travel as kernel arguments; when a frame is replayed
 // as a captured HIP graph (gs_set_graph_mode) they are read from this block in device memory instead, which the
@@ -74,6 +74,7 @@ constexpr int kBinSortLevels = 5;
 constexpr int kBinSlabLevel = 4;
 constexpr uint32_t kBinSortLimit[kBinSortLevels] = {4096, 8192, 12288, 16384, 65535};
 constexpr int kBinSortMax = 16384;
+constexpr uint32_t kSlabDescBytes = 288, kSlabCapacity = 8192, kSlabWorkGroups = 512;
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s);
 // fp32 SH block of the blob -> binary16 (round to nearest even), n x 48 values
@@ -123,6 +124,8 @@ struct BinLaunch {
     uint32_t* sorted_gid;       // [capacity (+4)]
     Counters* counters;
     uint32_t capacity;
+    void* slabs;                // [slab_capacity] 288-byte depth-slab descriptors (level 4)
+    uint32_t slab_capacity;
     uint32_t tiles_x, tiles_y, bins_x, bins_y;
     int bin_shift;              // log2 S
     int grid_shift;             // 4 or 5: padded bin id = by << grid_shift | bx

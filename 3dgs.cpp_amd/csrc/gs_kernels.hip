@@ -506,6 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         pu.counters->overflow = 0;
         pu.counters->bin_entries = 0;
         pu.counters->max_bin = 0;
+        pu.counters->slabs = 0;
     }
     preprocess_one(sv, u, av, i, i < sv.n, s_stage[threadIdx.x / WAVE]);
 }
@@ -1250,6 +1251,18 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
 //   beyond 16384 on the global depth-order path.
 //   !SORT: the candidates already are in depth order (global path) and are streamed from memory, any number.
 // ---------------------------------------------------------------------------------------
+// One depth slab of a dense bin, as k_bin_slabs (planning) hands it to k_slab_work: which records to select from the bin's
+// run and where each tile's list continues.
+struct SlabDesc {
+    uint32_t off, c_total;     // the bin's record run in the candidate buffer
+    uint32_t kmin;             // bucket of a key = (key - kmin) >> sh
+    int32_t sh;
+    uint32_t b_lo, b_hi;       // the slab's buckets
+    uint32_t pad[2];
+    uint32_t cur[64];          // per tile of the bin: where this slab's entries go in the list buffer
+};
+static_assert(sizeof(SlabDesc) == 288, "descriptor layout");
+
 struct BuildArgs {
     BinGrid g;
     uint32_t* cand;        // k_bin_build: [capacity] ids; k_bin_fast: [capacity] 12-byte records (rewritten in place in the degenerate-tie case)
@@ -1260,6 +1273,8 @@ struct BuildArgs {
     uint32_t* sorted_gid;  // [capacity]
     Counters* counters;
     uint32_t capacity;
+    SlabDesc* slabs;       // k_bin_slabs -> k_slab_work (level 4)
+    uint32_t slab_capacity;
 };
 
 // candidate's tile box clipped to the bin, in bin-local tile coordinates (upper bounds exclusive), packed like l1_item's
@@ -1614,13 +1629,16 @@ struct FastLayout {
     static constexpr int WORDS = 2 * MAXC + TAIL;
 };
 
-// SLABS: a bin of more than MAXC candidates (up to 65535) is taken in several rounds over the same LDS: its depth range is cut
-// into slabs of buckets holding <= MAXC candidates each (one pass for the depth range, one for the bucket histogram and the
-// per-tile totals -- which give the bin its list segment and the tile ranges up front --), and slab after slab the bin's
-// records are streamed again, the slab's members compacted into LDS, ordered, and appended to the tiles' lists behind what
-// the slabs in front of them wrote.  The slabs are depth-ordered and each is (depth, id)-ordered inside: so is the whole.
-template <int ROUNDS, bool SLABS = false>
+// Depth slabs (MODE 1 and 2): a bin of more than MAXC candidates (up to 65535) is cut along its depth range into slabs of
+// buckets holding <= MAXC candidates each.  MODE 1 (k_bin_slabs, one workgroup per bin) PLANS such a bin -- one pass over its
+// records for the depth range, one for the bucket histogram, the slab bounds, one for the per-slab per-tile counts, which give
+// the bin its list segment, the tile ranges and every slab its place in every tile's list -- and writes one descriptor per
+// slab; bins of <= MAXC it processes itself like MODE 0.  MODE 2 (k_slab_work, workgroups striding over the descriptors)
+// streams the bin's records once more, compacts the slab's members into LDS, orders them like a small bin and appends them at
+// the descriptor's cursors.  The slabs are depth-ordered and each is (depth, id)-ordered inside: so is every tile's list.
+template <int ROUNDS, int MODE = 0>
 __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
+    constexpr bool SLABS = MODE != 0;
     using L = FastLayout<ROUNDS>;
     constexpr int THREADS = L::THREADS, NW = L::NW, MAXC = L::MAXC;
     extern __shared__ uint32_t smem[];
@@ -1642,8 +1660,9 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1u;
     constexpr uint32_t kMaxInBin = SLABS ? 65535u : (uint32_t)MAXC;
     constexpr int kMaxSlabs = 12;
-    __shared__ uint32_t g_cur[SLABS ? 64 : 1], t_tot[SLABS ? 64 : 1];  // list cursors across the slabs; per-tile totals
+    __shared__ uint32_t g_cur[SLABS ? 64 : 1], t_tot[SLABS ? 64 : 1];  // a slab's list cursors; per-tile totals of the bin
     __shared__ uint32_t slab_first[SLABS ? kMaxSlabs + 1 : 1];         // first bucket of each slab
+    __shared__ uint32_t cnt2[MODE == 1 ? kMaxSlabs : 1][64];           // instances per slab and tile
     __shared__ uint32_t s_fill;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
@@ -1651,8 +1670,8 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // that exit at once upset the dispatcher's placement and a few CUs end up with three of the real ones)
     const uint32_t bin = ((blockIdx.x / a.g.bins_x) << a.g.grid_shift) | (blockIdx.x % a.g.bins_x);
     BUILD_T(0);
-    uint32_t c_total, off;
-    {   // this bin's count and offset (the padded grid has <= 1024 = THREADS bins)
+    uint32_t c_total = 0, off = 0;
+    if constexpr (MODE != 2) {  // this bin's count and offset (the padded grid has <= 1024 = THREADS bins)
         const uint32_t nb = 1u << (2 * a.g.grid_shift);
         const uint32_t v = (uint32_t)tid < nb ? a.bin_count[tid] : 0u;
         uint32_t tb, tm;
@@ -1671,15 +1690,14 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     }
     if (tid == 0) s_flag = 0;
     BUILD_T(1);
-    const bool multi = SLABS ? c_total > (uint32_t)MAXC : false;  // block-uniform
+#define multi (MODE == 2 ? true : (MODE == 1 ? c_total > (uint32_t)MAXC : false))  /* block-uniform */
     // c: the candidates in LDS (the whole bin, or the current slab of it); rounds / wbase follow it
     uint32_t c = multi ? 0u : c_total;
     int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= ROUNDS
     // this bin's run of 12-byte records {key, id, box16} as a raw buffer: 32-bit offsets (one address register per load instead
     // of two) and the hardware's bounds check in place of branches (reads past the run return 0)
     typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    uint32_t* const recs_ptr = a.cand + (size_t)kCandWords * off;
-#define recs uniform_rsrc(recs_ptr, c_total * 12u)  /* rebuilt from scalars at every use: see uniform_rsrc */
+#define recs uniform_rsrc(a.cand + (size_t)kCandWords * off, c_total * 12u)  /* rebuilt from scalars at every use: see uniform_rsrc */
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
     uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
@@ -1936,7 +1954,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // ---- a bin beyond MAXC: its depth range, the bucket histogram, the per-tile totals, the slabs
     uint32_t n_slabs = 1, g_kmin = 0;
     int g_sh = 0;
-    if constexpr (SLABS) if (multi) {
+    if constexpr (MODE == 1) if (multi) {
         uint32_t lo = 0xFFFFFFFFu, hi = 0u;
         for (uint32_t base = 0; base < c_total; base += 8 * THREADS) {  // pass 0: the keys' range (eight loads in flight)
             uint32_t k[8];
@@ -1954,24 +1972,17 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         const int bits = span ? 32 - __builtin_clz(span) : 0;
         g_sh = bits > 12 ? bits - 12 : 0;
         for (uint32_t k = tid; k < kMsdBuckets / 2; k += THREADS) m_cnt[k] = 0;
-        if (tid < 64) t_tot[tid] = 0;
+        for (uint32_t k = tid; k < (uint32_t)kMaxSlabs * 64u; k += THREADS) cnt2[k >> 6][k & 63u] = 0;
         __syncthreads();
-        for (uint32_t base = 0; base < c_total; base += 8 * THREADS) {  // pass 1: buckets and per-tile totals
-            uint32_t k[8], bx[8];
+        for (uint32_t base = 0; base < c_total; base += 8 * THREADS) {  // pass 1: the bucket histogram
+            uint32_t k[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const u32x3 rec = __builtin_amdgcn_raw_buffer_load_b96(recs, (base + r * THREADS + tid) * 12u, 0, 0);
-                k[r] = rec.x;
-                bx[r] = rec.z;
-            }
+            for (int r = 0; r < 8; ++r) k[r] = __builtin_amdgcn_raw_buffer_load_b32(recs, (base + r * THREADS + tid) * 12u, 0, 0);
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 if (base + r * THREADS + tid < c_total) {
                     const uint32_t bk = (k[r] - g_kmin) >> g_sh;
                     atomicAdd(&m_cnt[bk >> 1], 1u << (16u * (bk & 1u)));  // <= 65535 per bucket: no carry
-                    const uint32_t pb = bx[r], lx0 = pb & 15u, ly0 = (pb >> 4) & 15u, lx1 = (pb >> 8) & 15u, ly1 = (pb >> 12) & 15u;
-                    for (uint32_t y = ly0; y <= ly1; ++y)
-                        for (uint32_t x = lx0; x <= lx1; ++x) atomicAdd(&t_tot[(y << a.g.bin_shift) + x], 1u);
                 }
         }
         __syncthreads();
@@ -2022,8 +2033,62 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         }
         __syncthreads();
         if (tid == 0) s_flag = 0;
+        // pass 2: instances per slab and tile
+        for (uint32_t base = 0; n_slabs != 0 && base < c_total; base += 8 * THREADS) {
+            uint32_t k[8], bx[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const u32x3 rec = __builtin_amdgcn_raw_buffer_load_b96(recs, (base + r * THREADS + tid) * 12u, 0, 0);
+                k[r] = rec.x;
+                bx[r] = rec.z;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (base + r * THREADS + tid < c_total) {
+                    const uint32_t bk = (k[r] - g_kmin) >> g_sh;
+                    uint32_t sl = 0;
+                    for (uint32_t j = 1; j < n_slabs; ++j) sl += bk >= slab_first[j] ? 1u : 0u;
+                    const uint32_t pb = bx[r], lx0 = pb & 15u, ly0 = (pb >> 4) & 15u, lx1 = (pb >> 8) & 15u, ly1 = (pb >> 12) & 15u;
+                    for (uint32_t y = ly0; y <= ly1; ++y)
+                        for (uint32_t x = lx0; x <= lx1; ++x) atomicAdd(&cnt2[sl][(y << a.g.bin_shift) + x], 1u);
+                }
+        }
+        __syncthreads();
+        if (tid < 64) {  // per tile: the bin's total; cnt2 becomes the exclusive prefix over the slabs
+            uint32_t run = 0;
+            for (uint32_t k = 0; k < n_slabs; ++k) {
+                const uint32_t v = cnt2[k][tid];
+                cnt2[k][tid] = run;
+                run += v;
+            }
+            t_tot[tid] = run;
+        }
+        __syncthreads();
         place_lists(tid < 64 ? t_tot[tid] : 0u, g_cur);
         __syncthreads();
+        // one descriptor per slab; k_slab_work does the rest
+        if (tid == 0) {
+            const uint32_t base = n_slabs ? atomicAdd(&a.counters->slabs, n_slabs) : 0u;
+            s_seg0 = base;
+            if (base + n_slabs > a.slab_capacity) atomicOr(&a.counters->overflow, 2u);  // -> the global path
+        }
+        __syncthreads();
+        const uint32_t dbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seg0);
+        if (dbase + n_slabs <= a.slab_capacity) {
+            for (uint32_t k = 0; k < n_slabs; ++k) {
+                SlabDesc* d = a.slabs + dbase + k;
+                if (tid < 64) d->cur[tid] = g_cur[tid] + cnt2[k][tid];
+                if (tid == 64) {
+                    d->off = off;
+                    d->c_total = c_total;
+                    d->kmin = g_kmin;
+                    d->sh = g_sh;
+                    d->b_lo = slab_first[k];
+                    d->b_hi = slab_first[k + 1];
+                }
+            }
+        }
+        n_slabs = 0;  // nothing more to do for this bin here
     }
     // (a lambda, not a loop body: with a loop around it -- even one of a constant single trip -- the register allocator
     // of hipcc 7.2 spills 45 instead of 19 registers in k_bin_fast<12>)
@@ -2308,13 +2373,32 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     }
     if (multi && tid < 64) g_cur[tid] += t_cnt[tid];  // (t_cnt: this slab's per-tile counts; the next slab starts with a barrier)
     };
-    if constexpr (SLABS) {
-        for (uint32_t slab = 0; slab < n_slabs; ++slab) slab_body(slab);
-    } else {
+    if constexpr (MODE == 0) {
         slab_body(0u);
+    } else if constexpr (MODE == 1) {
+        if (n_slabs != 0) slab_body(0u);  // a bin of <= MAXC: one slab, the whole of it
+    } else {
+        const uint32_t n_desc = min(a.counters->slabs, a.slab_capacity);
+        for (uint32_t d = blockIdx.x; d < n_desc; d += gridDim.x) {
+            const SlabDesc* desc = a.slabs + d;
+            __syncthreads();  // the previous slab is done with LDS and the shared variables
+            off = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc->off);
+            c_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc->c_total);
+            g_kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc->kmin);
+            g_sh = __builtin_amdgcn_readfirstlane(desc->sh);
+            if (tid < 64) g_cur[tid] = desc->cur[tid];
+            if (tid == 0) {
+                slab_first[0] = desc->b_lo;
+                slab_first[1] = desc->b_hi;
+                s_flag = 0;
+            }
+            __syncthreads();
+            slab_body(0u);
+        }
     }
     BUILD_T(7);
 }
+#undef multi
 // 8 waves per SIMD for the two smaller sizes, i.e. two workgroups per CU: needs <= 64 VGPRs and <= 80 SGPRs (a SIMD has
 // 800 SGPRs, allocated in sixteens plus sixteen per wave); the attribute wants a literal, hence three kernels
 template <int ROUNDS> __global__ void k_bin_fast(BuildArgs a);
@@ -2322,8 +2406,9 @@ template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<4>(BuildArgs a
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<8>(BuildArgs a) { bin_fast_body<8>(a); }
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<12>(BuildArgs a) { bin_fast_body<12>(a); }
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<16>(BuildArgs a) { bin_fast_body<16>(a); }
-// bins of up to 65535 candidates, taken in slabs of <= 12288 (depth-order level 4)
-__global__ __launch_bounds__(1024, 4) void k_bin_slabs(BuildArgs a) { bin_fast_body<12, true>(a); }
+// bins of up to 65535 candidates, taken in depth slabs of <= 12288 (depth-order level 4): plan, then one workgroup per slab
+__global__ __launch_bounds__(1024, 4) void k_bin_slabs(BuildArgs a) { bin_fast_body<12, 1>(a); }
+__global__ __launch_bounds__(1024, 4) void k_slab_work(BuildArgs a) { bin_fast_body<12, 2>(a); }
 
 static L1Args l1_args(const BinLaunch& b) {
     L1Args a;
@@ -2401,6 +2486,9 @@ hipError_t bin_prepare_device() {  // once per device (gs_renderer::init)
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_slabs), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(FastLayout<12>::WORDS * sizeof(uint32_t)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_work), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FastLayout<12>::WORDS * sizeof(uint32_t)));
     return e;
 }
 
@@ -2423,6 +2511,8 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
     a.sorted_gid = b.sorted_gid;
     a.counters = b.counters;
     a.capacity = b.capacity;
+    a.slabs = reinterpret_cast<SlabDesc*>(b.slabs);
+    a.slab_capacity = b.slab_capacity;
     const uint32_t bins = b.bins_x * b.bins_y;  // on-screen bins: the kernels map the block index onto the padded grid
     const bool sort = level < kBinSortLevels;
     if (sort && b.bin_shift <= 3) {  // bins of 4 x 4 or 8 x 8 tiles: the all-in-LDS kernel, sized by the level
@@ -2430,7 +2520,10 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
         else if (level == 1) hipLaunchKernelGGL(k_bin_fast<8>, dim3(bins), dim3(1024), FastLayout<8>::WORDS * sizeof(uint32_t), s, a);
         else if (level == 2) hipLaunchKernelGGL(k_bin_fast<12>, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
         else if (level == 3) hipLaunchKernelGGL(k_bin_fast<16>, dim3(bins), dim3(1024), FastLayout<16>::WORDS * sizeof(uint32_t), s, a);
-        else hipLaunchKernelGGL(k_bin_slabs, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
+        else {
+            hipLaunchKernelGGL(k_bin_slabs, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
+            hipLaunchKernelGGL(k_slab_work, dim3(kSlabWorkGroups), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
+        }
     } else if (b.bin_shift <= 3) {
         launch_build<1>(a, sort, bins, s);
     } else if (b.bin_shift == 4) {
