@@ -952,6 +952,26 @@ __device__ __forceinline__ uint64_t cover_word(int shift, uint32_t box, int r) {
     return w;
 }
 
+// Which block of 1024 items a workgroup takes.  Workgroup b runs on XCD b % 8 (the dispatch rule the blend's tile order
+// relies on too) and every XCD has its own L2.  What the level-1 kernels write is fine-grained and block-major: a block's
+// 4-byte cell in each bin's row of the table (16 consecutive blocks to a line) and its run of a record or two in each bin's
+// list (a line holds 5 records).  Dealt out in launch order, the blocks that share a line sit on eight different XCDs and
+// every L2 evicts its own partial copy of it: WRITE_SIZE was 4 x the bytes stored at 6 M Gaussians.  So runs of
+// kL1XcdRun consecutive blocks go to the SAME XCD (the lines are completed in one L2), and the XCDs still advance through
+// the scene side by side.  The grid is rounded up to whole rounds of 8 runs; the blocks past the end return at once.
+#ifndef GS_L1_XCD_RUN
+#define GS_L1_XCD_RUN 32
+#endif
+constexpr uint32_t kL1XcdRun = GS_L1_XCD_RUN;  // 0: workgroup b takes block b
+__host__ __device__ constexpr uint32_t l1_grid(uint32_t nblk) {
+    return kL1XcdRun == 0 ? nblk : (nblk + 8u * kL1XcdRun - 1u) / (8u * kL1XcdRun) * (8u * kL1XcdRun);
+}
+__device__ __forceinline__ uint32_t l1_block() {
+    if (kL1XcdRun == 0) return blockIdx.x;
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    return ((j / kL1XcdRun) * 8u + xcd) * kL1XcdRun + j % kL1XcdRun;
+}
+
 // Wave w of the block takes chunks 4w .. 4w + 3 (consecutive items): all loads of its four chunks are issued before
 // the first is used, and 8 such blocks are resident per CU -- the kernels are a handful of dependent memory round
 // trips each, so what matters is how many of them are in flight.
@@ -961,6 +981,8 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
     __shared__ uint32_t s_hist[NB];
     __shared__ uint32_t s_vis;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const uint32_t blk = l1_block();
+    if (blk >= a.nblk) return;
     for (int b = tid; b < NB; b += BLOCK) s_hist[b] = 0;
     if (tid == 0) s_vis = 0;
     __syncthreads();
@@ -973,7 +995,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
         uint32_t box[kL1PerWave];
 #pragma unroll
         for (int j = 0; j < kL1PerWave; ++j)
-            l1_item(a, blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
+            l1_item(a, blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
 #pragma unroll
         for (int j = 0; j < kL1PerWave; ++j) s_box[w * kL1PerWave + j][lane] = box[j];
     }
@@ -1000,10 +1022,10 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
     if (lane == 0 && vis) atomicAdd(&s_vis, vis);
     __syncthreads();
     for (int b = tid; b < NB; b += BLOCK)
-        if (bin_on_screen(a.g, b)) a.hist[(size_t)b * a.nblk + blockIdx.x] = s_hist[b];
+        if (bin_on_screen(a.g, b)) a.hist[(size_t)b * a.nblk + blk] = s_hist[b];
     // V on the bin-local path (on the global path the first depth pass counts it): one more row of the table, summed
     // by k_l1_scan -- a thousand atomics on one counter would cost more than the rest of this kernel
-    if (tid == 0 && !a.order) a.hist[(size_t)NB * a.nblk + blockIdx.x] = s_vis;
+    if (tid == 0 && !a.order) a.hist[(size_t)NB * a.nblk + blk] = s_vis;
 }
 
 // One workgroup per bin: exclusive prefix of the bin's row of block counts (in place), row total -> bin_count.
@@ -1054,6 +1076,8 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
     __shared__ uint32_t s_ids[kL1Chunks][WAVE];
     __shared__ uint32_t scratch[8];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const uint32_t blk = l1_block();
+    if (blk >= a.nblk) return;
     {   // bin offsets = exclusive scan of the bin totals (<= 1024 values: every block redoes it, no extra launch)
         uint32_t c[NB / BLOCK], sum = 0;
 #pragma unroll
@@ -1066,11 +1090,11 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
 #pragma unroll
         for (int k = 0; k < NB / BLOCK; ++k) {
             const uint32_t b = tid * (NB / BLOCK) + k;
-            s_start[b] = off + (bin_on_screen(a.g, b) ? a.hist[(size_t)b * a.nblk + blockIdx.x] : 0u);
+            s_start[b] = off + (bin_on_screen(a.g, b) ? a.hist[(size_t)b * a.nblk + blk] : 0u);
             off += c[k];
-            if (blockIdx.x == 0 && c[k]) atomicMax(&a.counters->max_bin, c[k]);  // the fullest bin
+            if (blk == 0 && c[k]) atomicMax(&a.counters->max_bin, c[k]);  // the fullest bin
         }
-        if (blockIdx.x == 0 && tid == 0) {  // E1, candidate overflow
+        if (blk == 0 && tid == 0) {  // E1, candidate overflow
             a.counters->bin_entries = total;
             if (total > a.capacity) atomicOr(&a.counters->overflow, 1u);
         }
@@ -1082,7 +1106,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
         uint32_t box[kL1PerWave], gid[kL1PerWave];
 #pragma unroll
         for (int j = 0; j < kL1PerWave; ++j)
-            gid[j] = l1_item(a, blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
+            gid[j] = l1_item(a, blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
 #pragma unroll
         for (int j = 0; j < kL1PerWave; ++j) {
             s_ids[w * kL1PerWave + j][lane] = gid[j];
@@ -1163,6 +1187,8 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     __shared__ uint32_t s_cur[NB];  // next free slot of this block's run in each bin's list
     __shared__ uint32_t scratch[8];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const uint32_t blk = l1_block();
+    if (blk >= a.nblk) return;
     {   // bin offsets = exclusive scan of the bin totals (<= 1024 values: every block redoes it, no extra launch)
         uint32_t c[NB / BLOCK], sum = 0;
 #pragma unroll
@@ -1175,11 +1201,11 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
 #pragma unroll
         for (int k = 0; k < NB / BLOCK; ++k) {
             const uint32_t b = tid * (NB / BLOCK) + k;
-            s_cur[b] = off + (bin_on_screen(a.g, b) ? a.hist[(size_t)b * a.nblk + blockIdx.x] : 0u);
+            s_cur[b] = off + (bin_on_screen(a.g, b) ? a.hist[(size_t)b * a.nblk + blk] : 0u);
             off += c[k];
-            if (blockIdx.x == 0 && c[k]) atomicMax(&a.counters->max_bin, c[k]);  // the fullest bin
+            if (blk == 0 && c[k]) atomicMax(&a.counters->max_bin, c[k]);  // the fullest bin
         }
-        if (blockIdx.x == 0 && tid == 0) {  // E1, candidate overflow
+        if (blk == 0 && tid == 0) {  // E1, candidate overflow
             a.counters->bin_entries = total;
             if (total > a.capacity) atomicOr(&a.counters->overflow, 1u);
         }
@@ -1189,12 +1215,12 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     ushort4 tb[kL1PerWave];
 #pragma unroll
     for (int j = 0; j < kL1PerWave; ++j) {
-        const uint32_t p = blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+        const uint32_t p = blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
         nt[j] = p < a.n_bound ? a.tiles[p] : 0u;
     }
 #pragma unroll
     for (int j = 0; j < kL1PerWave; ++j) {
-        const uint32_t p = blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+        const uint32_t p = blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
         tb[j] = make_ushort4(0, 0, 0, 0);
         key[j] = 0;
         if (nt[j] != 0) {
@@ -1214,7 +1240,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     };
 #pragma unroll
     for (int j = 0; j < kL1PerWave; ++j) {
-        const uint32_t gid = blockIdx.x * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+        const uint32_t gid = blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
         uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         if (nt[j] != 0) {
             x0 = tb[j].x >> a.g.bin_shift, y0 = tb[j].y >> a.g.bin_shift;
@@ -2433,8 +2459,8 @@ uint32_t bin_level1_blocks(uint32_t n_items) { return (n_items + kL1Items - 1) /
 void launch_bin_level1_count(const BinLaunch& b, hipStream_t s) {
     const L1Args a = l1_args(b);
     if (a.nblk == 0) return;
-    if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_hist<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
-    else hipLaunchKernelGGL(k_l1_hist<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+    if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_hist<4>, dim3(l1_grid(a.nblk)), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(k_l1_hist<16>, dim3(l1_grid(a.nblk)), dim3(BLOCK), 0, s, a);
     hipLaunchKernelGGL(k_l1_scan, dim3((1u << (2 * b.grid_shift)) + 1u), dim3(BLOCK), 0, s, a);
 }
 
@@ -2442,11 +2468,11 @@ void launch_bin_level1_scatter(const BinLaunch& b, bool any_order, hipStream_t s
     const L1Args a = l1_args(b);
     if (a.nblk == 0) return;
     if (any_order) {
-        if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_scatter_any_order<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
-        else hipLaunchKernelGGL(k_l1_scatter_any_order<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+        if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_scatter_any_order<4>, dim3(l1_grid(a.nblk)), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(k_l1_scatter_any_order<16>, dim3(l1_grid(a.nblk)), dim3(BLOCK), 0, s, a);
     } else {
-        if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_scatter<4>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
-        else hipLaunchKernelGGL(k_l1_scatter<16>, dim3(a.nblk), dim3(BLOCK), 0, s, a);
+        if (b.grid_shift == 4) hipLaunchKernelGGL(k_l1_scatter<4>, dim3(l1_grid(a.nblk)), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(k_l1_scatter<16>, dim3(l1_grid(a.nblk)), dim3(BLOCK), 0, s, a);
     }
 }
 
