@@ -443,6 +443,9 @@ void load_ply_streamed(gs_scene* s, const std::string& path) {
 // ------------------------------------------------------------------------------------------
 // gs_renderer
 // ------------------------------------------------------------------------------------------
+#ifndef GS_L1_DENSE
+#define GS_L1_DENSE 1  // 0 (A/B builds): level 1 walks the N-wide planes as in round 2
+#endif
 // One complete set of per-frame device buffers + the stream its passes run on.  Frames alternate between
 // sets, so with >= 2 sets the small launch-bound passes of frame i+1 (scans, binning) overlap the
 // VALU-bound blend of frame i on the same GPU.
@@ -457,6 +460,9 @@ struct FrameBuffers {
     DevBuf<float> depth;
     DevBuf<ushort4> aabb;
     DevBuf<gs::AttrRecord> rec;  // one 64-byte record per Gaussian: what the blend gathers
+    DevBuf<uint4> vis;           // the frame's visible Gaussians as dense lists (gs::AttrView::vis): level 1's input on the bin-local path
+    DevBuf<uint32_t> vis_count;  // the lists' counters, one per 128 bytes
+    uint32_t vis_region_slots = 0;
     // global depth order (only allocated when that path is taken)
     DevBuf<uint32_t> dkeys[2], dvals[2];
     DevBuf<uint32_t> block_hist, digit_total;
@@ -501,7 +507,11 @@ struct FrameBuffers {
         depth.alloc(n);
         aabb.alloc(n);
         rec.alloc(n);
-        l1_hist.alloc(1025 * static_cast<size_t>(gs::bin_level1_blocks(static_cast<uint32_t>(n))));  // + the row of visible counts
+        vis_region_slots = gs::vis_region_slots(static_cast<uint32_t>(n));
+        vis.alloc(static_cast<size_t>(gs::kVisRegions) * vis_region_slots);
+        vis_count.alloc(gs::kVisRegions * gs::kVisCounterStride);
+        HIP_CHECK(hipMemset(vis_count.p, 0, vis_count.n * sizeof(uint32_t)));  // every frame's LAST kernel zeroes them again
+        l1_hist.alloc(1025 * static_cast<size_t>(gs::bin_level1_columns(static_cast<uint32_t>(n))));  // + the row of visible counts
         bin_count.alloc(1024);
         counters.alloc(1);
         params.alloc(1);
@@ -590,6 +600,11 @@ struct gs_renderer {
     int exp_mode = 2;            // the blend's exp(): 2 libm's expf restated in binary64 (default), 0 pipeline polynomial, 1 hardware v_exp_f32 (gs_set_exp_mode)
     bool contract = false;       // the three FMA contractions GLSL permits in render.comp:66,87 (gs_set_blend_contraction); default: as written
     int min_bin_shift = 3;       // GS_BIN_SHIFT: log2 of the default bin edge in tiles (8 x 8 tiles)
+    // GS_L1_DENSE_MIN: scenes of at least this many Gaussians hand level 1 the dense lists of visible Gaussians (measured
+    // A/B, profiles/r03_l1_dense_lists_ab.txt: 6 M Gaussians +2 % one frame at a time, +2..7 % with three in flight --
+    // level 1 is several rounds of workgroups there; 1 M: -0.5 %, level 1 is one round of workgroups bound by its round
+    // trips and k_preprocess pays 2 us for the lists).  The GPU tests set it to 0 for small scenes.
+    uint64_t dense_min = 2u << 20;
     bool refined = false;        // bins of half that edge: taken when a bin outgrows the largest in-LDS order
     bool have_frame = false;
     uint32_t retries = 0;        // lifetime count of re-run frames (statistics only)
@@ -760,8 +775,13 @@ struct gs_renderer {
 
         gs::SceneView sv{scene->blob, scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n)),
                           scene->sh_half ? scene->sh16.p : nullptr};
-        gs::AttrView av{fb.tiles.p, fb.depth.p, fb.aabb.p, fb.rec.p};
         gs::Counters* cnt = fb.counters.p;
+        // the level-1 kernels that take their items in any order (bin-local path, bins of <= 8 x 8 tiles) stream the dense
+        // list of visible Gaussians, which k_preprocess then writes beside the planes
+        const bool l1_any_order = bin_local && geo.bin_shift <= 3;
+        const bool dense_list = GS_L1_DENSE && l1_any_order && n != 0 && n >= dense_min && u.width != 0 && u.height != 0;  // (the blend zeroes the lists' counters)
+        gs::AttrView av{fb.tiles.p, fb.depth.p, fb.aabb.p, fb.rec.p, dense_list ? fb.vis.p : nullptr, dense_list ? fb.vis_count.p : nullptr,
+                        fb.vis_region_slots};
 
         // the first and the last kernel of the frame clear / publish the counters themselves; the blit nodes (and
         // their fences) are only needed when one of the two is not launched
@@ -811,6 +831,9 @@ struct gs_renderer {
                 b.tiles = fb.tiles.p;
                 b.aabb = fb.aabb.p;
                 b.depth = fb.depth.p;
+                b.vis = av.vis;
+                b.vis_count = av.vis_count;
+                b.vis_region_slots = av.vis_region_slots;
                 b.hist = fb.l1_hist.p;
                 b.bin_count = fb.bin_count.p;
                 b.cand = fb.cand.p;
@@ -829,7 +852,7 @@ struct gs_renderer {
                 // ---- level 1: which Gaussian touches which bin (count + scan, then the per-bin candidate lists) ----
                 gs::launch_bin_level1_count(b, stream);
                 if (spans) HIP_CHECK(hipEventRecord(ev[3], stream));
-                gs::launch_bin_level1_scatter(b, bin_local && geo.bin_shift <= 3, stream);
+                gs::launch_bin_level1_scatter(b, l1_any_order, stream);
                 if (spans) HIP_CHECK(hipEventRecord(ev[4], stream));
                 // ---- level 2: order inside the bin (bin-local path), tile ranges, per-tile lists ----
                 gs::launch_bin_level2(b, lv, stream);
@@ -1220,6 +1243,7 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
         if (const char* e = std::getenv("GS_GRAPH")) r->graph_mode = std::atoi(e) != 0;  // initial gs_set_graph_mode
         if (const char* e = std::getenv("GS_EXP_MODE")) r->exp_mode = std::min(2, std::max(0, std::atoi(e)));  // initial gs_set_exp_mode
         if (const char* e = std::getenv("GS_BLEND_CONTRACTION")) r->contract = std::atoi(e) != 0;  // initial gs_set_blend_contraction
+        if (const char* e = std::getenv("GS_L1_DENSE_MIN")) r->dense_min = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("GS_BIN_SHIFT")) r->min_bin_shift = std::min(5, std::max(2, std::atoi(e)));  // default bin edge
         if (const char* e = std::getenv("GS_SORT_PATH")) {  // initial gs_set_sort_path, for hosts that cannot call it (the viewer)
             const int mode = std::atoi(e);

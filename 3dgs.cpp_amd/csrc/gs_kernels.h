@@ -47,7 +47,20 @@ struct AttrView {
     float* depth;
     ushort4* aabb;
     AttrRecord* rec;     // written for visible Gaussians only
+    // Optional (null: not written): the frame's visible Gaussians as DENSE lists in any order, 16 bytes each --
+    // {id, depth bits, tile box x0 | y0 << 16, x1 | y1 << 16} -- which the level-1 kernels of the bin-local path stream
+    // instead of walking the N-wide planes above (half of whose lanes are culled) with a dependent gather behind them.
+    // kVisRegions lists of vis_region_slots slots each: workgroup b of k_preprocess appends to list b % kVisRegions, a wave
+    // taking its run of slots with ONE atomic add on the list's counter, vis_count[region * kVisCounterStride].  (One list
+    // with one counter was measured first: 94 k same-address atomics per frame at 6 M Gaussians retire at ~10 ns each and
+    // k_preprocess took 1.1 ms instead of 0.27.)  The frame's last kernel (k_blend) zeroes the counters for the next frame.
+    uint4* vis;
+    uint32_t* vis_count;
+    uint32_t vis_region_slots;
 };
+constexpr uint32_t kVisRegions = 256, kVisCounterStride = 32;  // a counter per 128 bytes
+// slots per list for a scene of n Gaussians: what the workgroups (of 256) that append to it can hold, a whole number of level-1 blocks
+uint32_t vis_region_slots(uint32_t n);
 
 // Device-resident frame counters.
 struct Counters {
@@ -117,7 +130,10 @@ struct BinLaunch {
     const uint32_t* tiles;      // [N]
     const ushort4* aabb;        // [N]
     const float* depth;         // [N]
-    uint32_t* hist;             // [padded bins + 1][bin_level1_blocks(n_bound)] (the last row: visible items per block)
+    const uint4* vis;           // null, or (any-order scatter only) AttrView::vis / vis_count / vis_region_slots: the items are the lists' entries
+    uint32_t* vis_count;
+    uint32_t vis_region_slots;
+    uint32_t* hist;             // [padded bins + 1][bin_level1_columns(n_bound)] (the last row: visible items per block)
     uint32_t* bin_count;        // [1024]
     uint32_t* cand;             // [capacity]
     uint32_t* ranges;           // [T][2]
@@ -131,6 +147,7 @@ struct BinLaunch {
     int grid_shift;             // 4 or 5: padded bin id = by << grid_shift | bx
 };
 uint32_t bin_level1_blocks(uint32_t n_items);
+uint32_t bin_level1_columns(uint32_t n_items);  // columns of the hist table: level-1 blocks over the planes or over the dense lists, whichever is more
 void bin_debug_occupancy();
 hipError_t bin_prepare_device();                                    // once per device, before the first launch_bin_level2
 void launch_bin_level1_count(const BinLaunch& b, hipStream_t s);    // k_l1_hist, k_l1_scan

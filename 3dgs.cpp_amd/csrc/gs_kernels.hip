@@ -373,6 +373,16 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
     } while (false);
     const bool vis = num_tiles != 0;
 
+    // ---- the wave's run of slots in its workgroup's dense list of visible Gaussians (AttrView::vis): one atomic per wave,
+    // issued here, its result first needed after the SH work below -- the round trip rides behind the SH fetch
+    uint32_t vis_base = 0;
+    if (av.vis) {
+        const uint64_t m = __ballot(vis);
+        const uint32_t region = (i / BLOCK) % kVisRegions;  // (i / BLOCK = the workgroup)
+        if (lane == 0 && m != 0)
+            vis_base = region * av.vis_region_slots + atomicAdd(av.vis_count + region * kVisCounterStride, (uint32_t)__popcll(m));
+    }
+
     // ---- the SH block of the visible Gaussians: 48 contiguous floats each (192 B = three 64-byte lines); only lanes
     // that survived every cull need them, so SH traffic is 192 B per VISIBLE Gaussian.
     float rgb[3] = {0.0f, 0.0f, 0.0f};
@@ -476,6 +486,12 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
     // lanes write one record -- ONE 64-byte request per visible Gaussian (the last quarter as zeros) instead of three
     // 16-byte ones from its own lane: k_preprocess 39 -> 37 us (without any record store it takes 30).
     const uint64_t vm = __ballot(vis);
+    if (av.vis) {  // 16 bytes per visible Gaussian, the wave's entries back to back
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)vis_base);
+        if (vis)
+            av.vis[base + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] =
+                make_uint4(i, __float_as_uint(depth), (uint32_t)bx0 | ((uint32_t)by0 << 16), (uint32_t)bx1 | ((uint32_t)by1 << 16));
+    }
     if (vis) {
         stage[0 * kPrePlane + lane] = make_float4(c00, c01, c11, opacity);
         stage[1 * kPrePlane + lane] = make_float4(uvx, uvy, rgb[0], rgb[1]);
@@ -906,6 +922,9 @@ struct L1Args {
     const uint32_t* tiles;      // [N] tiles_overlap (0 = culled)
     const ushort4* aabb;        // [N] tile boxes
     const float* depth;         // [N] (the record-emitting scatter only)
+    const uint4* vis;           // null, or the dense lists of visible Gaussians (AttrView::vis): then the items are their entries
+    const uint32_t* vis_count;
+    uint32_t vis_region_slots;  // slots per list = kL1Items x (level-1 blocks per list)
     uint32_t* hist;             // [bins (padded)][nblk]
     uint32_t* bin_count;        // [bins (padded)]
     uint32_t* cand;             // [capacity] bin-major candidate Gaussian ids
@@ -933,6 +952,21 @@ __device__ __forceinline__ uint32_t l1_item(const L1Args& a, uint32_t p, uint32_
         }
     }
     return gid;
+}
+// Dense lists: level-1 block `blk` covers slots [first, first + kL1Items) of list blk / (blocks per list); returns how many of
+// them hold an entry (0: the block has nothing to do, and its cells of the table are never read).
+__device__ __forceinline__ uint32_t l1_vis_block(const L1Args& a, uint32_t blk, uint32_t& first) {
+    const uint32_t per = a.vis_region_slots / kL1Items, region = blk / per, at = (blk % per) * kL1Items;
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.vis_count[region * kVisCounterStride]);
+    if (cnt > a.vis_region_slots) cnt = a.vis_region_slots;  // (cannot happen: a list holds what its workgroups can append)
+    first = region * a.vis_region_slots + at;
+    return cnt > at ? (cnt - at < (uint32_t)kL1Items ? cnt - at : (uint32_t)kL1Items) : 0u;
+}
+// tile box of a dense-list entry {id, depth bits, x0 | y0 << 16, x1 | y1 << 16} -> box in bin coordinates, packed like l1_item's
+__device__ __forceinline__ uint32_t l1_bin_box(const L1Args& a, uint4 r) {
+    const uint32_t x0 = (r.z & 0xFFFFu) >> a.g.bin_shift, y0 = (r.z >> 16) >> a.g.bin_shift;
+    const uint32_t x1 = (((r.w & 0xFFFFu) - 1u) >> a.g.bin_shift) + 1u, y1 = (((r.w >> 16) - 1u) >> a.g.bin_shift) + 1u;
+    return x0 | (y0 << 8) | (x1 << 16) | (y1 << 24);
 }
 template <int R>
 __device__ __forceinline__ void packed_cover_masks(int shift, uint32_t box, uint64_t (&m)[R]) {
@@ -983,19 +1017,36 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const uint32_t blk = l1_block();
     if (blk >= a.nblk) return;
+    uint32_t n = a.n_items ? *a.n_items : a.n_bound;
+    if (n > a.n_bound) n = a.n_bound;
+    uint32_t vis_first = 0;
+    const uint32_t vis_here = a.vis ? l1_vis_block(a, blk, vis_first) : 0u;
+    if (a.vis && vis_here == 0) return;
     for (int b = tid; b < NB; b += BLOCK) s_hist[b] = 0;
     if (tid == 0) s_vis = 0;
     __syncthreads();
-    uint32_t n = a.n_items ? *a.n_items : a.n_bound;
-    if (n > a.n_bound) n = a.n_bound;
     // all four items' loads first (independent round trips), then one chunk at a time: the chunk body holds up to 16
     // inlined transposes and must not be unrolled four times over (the instruction cache is 64 KiB)
     __shared__ uint32_t s_box[kL1Chunks][WAVE];
     {
         uint32_t box[kL1PerWave];
+        if (a.vis) {  // dense items: one 16-byte load each, no culled lanes but in the list's last block
+            uint4 r[kL1PerWave];
 #pragma unroll
-        for (int j = 0; j < kL1PerWave; ++j)
-            l1_item(a, blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
+            for (int j = 0; j < kL1PerWave; ++j) {
+                const uint32_t q = (w * kL1PerWave + j) * WAVE + lane;
+                r[j] = q < vis_here ? a.vis[vis_first + q] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < kL1PerWave; ++j) {
+                const uint32_t q = (w * kL1PerWave + j) * WAVE + lane;
+                box[j] = q < vis_here ? l1_bin_box(a, r[j]) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kL1PerWave; ++j)
+                l1_item(a, blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane, n, box[j]);
+        }
 #pragma unroll
         for (int j = 0; j < kL1PerWave; ++j) s_box[w * kL1PerWave + j][lane] = box[j];
     }
@@ -1025,7 +1076,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
         if (bin_on_screen(a.g, b)) a.hist[(size_t)b * a.nblk + blk] = s_hist[b];
     // V on the bin-local path (on the global path the first depth pass counts it): one more row of the table, summed
     // by k_l1_scan -- a thousand atomics on one counter would cost more than the rest of this kernel
-    if (tid == 0 && !a.order) a.hist[(size_t)NB * a.nblk + blk] = s_vis;
+    if (tid == 0 && !a.order && !a.vis) a.hist[(size_t)NB * a.nblk + blk] = s_vis;
 }
 
 // One workgroup per bin: exclusive prefix of the bin's row of block counts (in place), row total -> bin_count.
@@ -1035,6 +1086,14 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scan(L1Args a) {
     const uint32_t nb = 1u << (2 * a.g.grid_shift);
     if (bin == nb) {  // the row of per-block visible counts (bin-local path): V
         if (a.order) return;
+        if (a.vis) {  // the dense lists' lengths add up to V
+            uint32_t c = threadIdx.x < kVisRegions ? a.vis_count[threadIdx.x * kVisCounterStride] : 0u;
+            if (c > a.vis_region_slots) c = a.vis_region_slots;
+            uint32_t total;
+            block_excl_scan<BLOCK>(c, scratch, &total);
+            if (threadIdx.x == 0) a.counters->visible = total;
+            return;
+        }
         uint32_t sum = 0;
         for (uint32_t i = threadIdx.x; i < a.nblk; i += BLOCK) sum += a.hist[(size_t)nb * a.nblk + i];
         uint32_t total;
@@ -1047,20 +1106,33 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scan(L1Args a) {
         return;
     }
     uint32_t* row = a.hist + (size_t)bin * a.nblk;
+    // dense lists: only the blocks that had entries wrote their cell (the first ceil(count / kL1Items) of every list)
+    __shared__ uint32_t s_used[kVisRegions];  // per list: blocks with entries
+    const uint32_t per = a.vis ? a.vis_region_slots / kL1Items : 1u;
+    if (a.vis) {
+        if (threadIdx.x < kVisRegions) {
+            uint32_t c = a.vis_count[threadIdx.x * kVisCounterStride];
+            if (c > a.vis_region_slots) c = a.vis_region_slots;
+            s_used[threadIdx.x] = (c + kL1Items - 1) / kL1Items;
+        }
+        __syncthreads();
+    }
     uint32_t running = 0;
     for (uint32_t base = 0; base < a.nblk; base += 4 * BLOCK) {
         const uint32_t i0 = base + threadIdx.x * 4;
         uint32_t v[4], sum = 0;
+        bool live[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[k] = i0 + k < a.nblk ? row[i0 + k] : 0u;
+            live[k] = i0 + k < a.nblk && (!a.vis || (i0 + k) % per < s_used[(i0 + k) / per]);
+            v[k] = live[k] ? row[i0 + k] : 0u;
             sum += v[k];
         }
         uint32_t total;
         uint32_t excl = running + block_excl_scan<BLOCK>(sum, scratch, &total);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (i0 + k < a.nblk) row[i0 + k] = excl;
+            if (live[k]) row[i0 + k] = excl;
             excl += v[k];
         }
         running += total;
@@ -1189,6 +1261,9 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const uint32_t blk = l1_block();
     if (blk >= a.nblk) return;
+    uint32_t vis_first = 0;
+    const uint32_t vis_here = a.vis ? l1_vis_block(a, blk, vis_first) : 0u;
+    if (a.vis && blk != 0 && vis_here == 0) return;  // (block 0 always reports E1 and the fullest bin)
     {   // bin offsets = exclusive scan of the bin totals (<= 1024 values: every block redoes it, no extra launch)
         uint32_t c[NB / BLOCK], sum = 0;
 #pragma unroll
@@ -1210,22 +1285,42 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
             if (total > a.capacity) atomicOr(&a.counters->overflow, 1u);
         }
     }
-    // all four items' loads first (two dependent round trips: tiles, then box + depth of the visible ones)
-    uint32_t nt[kL1PerWave], key[kL1PerWave];
+    // all four items' loads first.  Dense list: one 16-byte load per item; else two dependent round trips over the N-wide
+    // planes: tiles, then box + depth of the visible ones
+    uint32_t nt[kL1PerWave], key[kL1PerWave], ids[kL1PerWave];
     ushort4 tb[kL1PerWave];
+    if (a.vis) {
+        uint4 r[kL1PerWave];
 #pragma unroll
-    for (int j = 0; j < kL1PerWave; ++j) {
-        const uint32_t p = blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
-        nt[j] = p < a.n_bound ? a.tiles[p] : 0u;
-    }
+        for (int j = 0; j < kL1PerWave; ++j) {
+            const uint32_t q = (w * kL1PerWave + j) * WAVE + lane;
+            r[j] = q < vis_here ? a.vis[vis_first + q] : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
-    for (int j = 0; j < kL1PerWave; ++j) {
-        const uint32_t p = blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
-        tb[j] = make_ushort4(0, 0, 0, 0);
-        key[j] = 0;
-        if (nt[j] != 0) {
-            tb[j] = a.aabb[p];
-            key[j] = __float_as_uint(a.depth[p]);
+        for (int j = 0; j < kL1PerWave; ++j) {
+            const uint32_t q = (w * kL1PerWave + j) * WAVE + lane;
+            nt[j] = q < vis_here ? 1u : 0u;
+            ids[j] = r[j].x;
+            key[j] = r[j].y;
+            tb[j] = make_ushort4((unsigned short)(r[j].z & 0xFFFFu), (unsigned short)(r[j].z >> 16), (unsigned short)(r[j].w & 0xFFFFu),
+                                 (unsigned short)(r[j].w >> 16));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kL1PerWave; ++j) {
+            const uint32_t p = blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+            nt[j] = p < a.n_bound ? a.tiles[p] : 0u;
+            ids[j] = p;
+        }
+#pragma unroll
+        for (int j = 0; j < kL1PerWave; ++j) {
+            const uint32_t p = blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+            tb[j] = make_ushort4(0, 0, 0, 0);
+            key[j] = 0;
+            if (nt[j] != 0) {
+                tb[j] = a.aabb[p];
+                key[j] = __float_as_uint(a.depth[p]);
+            }
         }
     }
     __syncthreads();
@@ -1240,7 +1335,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     };
 #pragma unroll
     for (int j = 0; j < kL1PerWave; ++j) {
-        const uint32_t gid = blk * kL1Items + (w * kL1PerWave + j) * WAVE + lane;
+        const uint32_t gid = ids[j];
         uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         if (nt[j] != 0) {
             x0 = tb[j].x >> a.g.bin_shift, y0 = tb[j].y >> a.g.bin_shift;
@@ -2445,16 +2540,30 @@ static L1Args l1_args(const BinLaunch& b) {
     a.tiles = b.tiles;
     a.aabb = b.aabb;
     a.depth = b.depth;
+    a.vis = b.vis;
+    a.vis_count = b.vis_count;
+    a.vis_region_slots = b.vis_region_slots;
     a.hist = b.hist;
     a.bin_count = b.bin_count;
     a.cand = b.cand;
     a.counters = b.counters;
     a.capacity = b.capacity;
-    a.nblk = bin_level1_blocks(b.n_bound);
+    // level-1 blocks: over the N items, or over the slots of the dense lists
+    a.nblk = b.vis ? kVisRegions * (b.vis_region_slots / kL1Items) : bin_level1_blocks(b.n_bound);
     return a;
 }
 
 uint32_t bin_level1_blocks(uint32_t n_items) { return (n_items + kL1Items - 1) / kL1Items; }
+uint32_t vis_region_slots(uint32_t n) {
+    const uint32_t groups = (n + BLOCK - 1) / BLOCK, per_region = (groups + kVisRegions - 1) / kVisRegions;  // k_preprocess workgroups per list
+    const uint32_t slots = per_region * BLOCK;
+    return slots == 0 ? kL1Items : (slots + kL1Items - 1) / kL1Items * kL1Items;
+}
+uint32_t bin_level1_columns(uint32_t n_items) {
+    const uint32_t dense = kVisRegions * (vis_region_slots(n_items) / kL1Items), planes = bin_level1_blocks(n_items);
+    return dense > planes ? dense : planes;
+}
+static_assert(BLOCK >= (int)kVisRegions, "k_blend's first workgroup zeroes the list counters, k_l1_scan's sums them: a thread each");
 
 void launch_bin_level1_count(const BinLaunch& b, hipStream_t s) {
     const L1Args a = l1_args(b);
@@ -2699,7 +2808,7 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
                                                  float4* __restrict__ rgba, uchar4* __restrict__ bgra,
                                                  const Counters* __restrict__ counters, Counters* host_counters,
-                                                 const FrameParams* __restrict__ fp) {
+                                                 const FrameParams* __restrict__ fp, uint32_t* __restrict__ vis_count) {
     if (fp) {  // graph replay: this frame's targets come from the parameter block
         rgba = reinterpret_cast<float4*>(fp->rgba);
         bgra = reinterpret_cast<uchar4*>(fp->bgra);
@@ -2721,6 +2830,8 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     // last kernel of the frame: hand V, D, E1 and the overflow flag to the host (pinned memory; visible to it once
     // the frame's completion event, which carries the system-scope release, has fired) -- no copy node in the stream
     if (host_counters && blockIdx.x == 0 && tid == 0) *host_counters = *counters;
+    // ... and k_preprocess of the next frame on these buffers appends to the dense lists of visible Gaussians from zero again
+    if (vis_count && blockIdx.x == 0 && (uint32_t)tid < kVisRegions) vis_count[(uint32_t)tid * kVisCounterStride] = 0;
     // XCD-aware, load-balanced tile order: a host-built table (gs_capi.cpp, ensure_tile_order)
     const uint32_t tile = tile_order[blockIdx.x];
     const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -2925,7 +3036,7 @@ static void launch_blend_as(const uint32_t* ranges, const uint32_t* sorted_gid, 
                             const Counters* counters, Counters* host_counters, const FrameParams* fp, hipStream_t s) {
     hipLaunchKernelGGL((k_blend<EXP, CONTRACT>), dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                        sorted_gid, tile_order, av.rec, width, height, tx, reinterpret_cast<float4*>(rgba),
-                       reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp);
+                       reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp, av.vis_count);
 }
 
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,

@@ -100,6 +100,48 @@ def test_rotated_translated_camera(pkg, oracle, gpu):
     assert np.abs(img - ref["image"]).max() <= PIXEL_TOL
 
 
+@pytest.mark.parametrize("dense_min", ["0", "1000000000"])
+def test_level1_over_the_dense_lists_and_over_the_planes(pkg, oracle, gpu, monkeypatch, dense_min):
+    """Level 1 of the bin-local path takes its items from the dense lists of visible Gaussians k_preprocess appends to
+    (scenes of >= GS_L1_DENSE_MIN Gaussians; default 2 M, so the small scenes of this file would never use them) or from the
+    N-wide planes.  Both forced here on the same scenes: stages and pixels equal the oracle's; the lists' counters are
+    zeroed by each frame's last kernel, so frame after frame on the same buffers -- serial, four in flight, after an
+    overflow re-run, after a resolution change -- must stay equal."""
+    monkeypatch.setenv("GS_L1_DENSE_MIN", dense_min)
+    rec = pkg.synth.synth_records(10000, seed=0, kind="A")
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, 256, 256)
+    compare_stages(pkg, rend, u, ref)
+    for _ in range(3):
+        again, _ = rend.render_host(u)
+        np.testing.assert_array_equal(again.view(np.uint32), ref["image"].view(np.uint32))
+    assert rend.stats().num_visible == int((ref["tiles"] != 0).sum())
+    # many bins, a few splats that cover many of them (the wave-cooperative emission), 300 level-1 blocks' worth of lists
+    rec = pkg.synth.synth_records(300000, seed=17, kind="A")
+    rec[:40, 55:58] = 0.5
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, 1920, 1080)
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+    # other poses on the same renderer, four frames in flight, then a smaller target
+    w, h = 1920, 1080
+    poses = [pkg.camera_uniforms(pkg.make_camera(rotation=pkg.dist.pose_quaternion(k, 3.0)), w, h) for k in range(6)]
+    serial = [rend.render_host(p)[0] for p in poses]
+    rend.set_frames_in_flight(4)
+    dev = _HipBuffers()
+    outs = [dev.alloc(w * h * 16) for _ in poses]
+    for p, o in zip(poses, outs):
+        rend.render(p, o, 0)
+    rend.synchronize()
+    for s_img, o in zip(serial, outs):
+        np.testing.assert_array_equal(dev.download(o, (h, w, 4), np.float32), s_img)
+    dev.close()
+    ref3 = oracle.stages(oracle.activate_records(rec), poses[3].view(oracle.UNIFORMS_DT))["image"]
+    np.testing.assert_array_equal(serial[3].view(np.uint32), ref3.view(np.uint32))
+    u_small = pkg.camera_uniforms(pkg.make_camera(), 640, 360)
+    small, _ = rend.render_host(u_small)
+    ref_small = oracle.stages(oracle.activate_records(rec), u_small.view(oracle.UNIFORMS_DT))["image"]
+    np.testing.assert_array_equal(small.view(np.uint32), ref_small.view(np.uint32))
+
+
 def test_empty_and_all_culled(pkg, oracle, gpu):
     # every Gaussian behind the camera: D = 0, black frame (SURVEY §8a edge cases)
     rec = pkg.synth.synth_records(500, seed=2, kind="A")

@@ -1,15 +1,17 @@
 #!/bin/bash
-# A/B of the XCD-aware level-1 block order (GS_L1_XCD_RUN=32, the default) against launch order (libgs3d_hip_l1flat.so,
-# `make variant TAG=l1flat DEFS=-DGS_L1_XCD_RUN=0`), interleaved on one box; every frame must equal the first bit for bit.
-#   gpurun --timeout 420 -- 'bash tools/r03_l1xcd_ab.sh'
+# A/B of a level-1 variant build against the default library, interleaved on one box; every frame must equal the first bit for bit.
+#   l1flat   launch-order blocks instead of runs of 32 per XCD   (make variant TAG=l1flat DEFS=-DGS_L1_XCD_RUN=0)
+#   nodense  level 1 walks the N-wide planes instead of the dense list of visible Gaussians   (make variant TAG=nodense DEFS=-DGS_L1_DENSE=0)
+#   gpurun --timeout 420 -- 'bash tools/r03_l1_ab.sh nodense "1 2"'
 R=$(pwd); O=$R/gpurun_out; P=$R/3dgs.cpp_amd; exec < /dev/null
 mkdir -p "$O"
-LOG=$O/r03_l1xcd_ab.txt
+OTHER=${1:-l1flat}; REPS=${2:-"1 2"}
+LOG=$O/r03_l1_ab_$OTHER.txt
 : > "$LOG"
 run() {  # name, args
   local name=$1; shift
   rm -f /tmp/ab_ref.npy
-  for rep in 1 2; do for v in cur l1flat; do
+  for rep in $REPS; do for v in cur $OTHER; do
     L=$P/libgs3d_hip_$v.so; [ "$v" = cur ] && L=$P/libgs3d_hip.so
     echo "== $name $v (run $rep)" >> "$LOG"
     GS3D_HIP_LIB=$L timeout 100 python tools/tune_sweep.py --quick --ref-image /tmp/ab_ref.npy "$@" 2>&1 | grep -v "^$" | tail -5 >> "$LOG"
@@ -19,5 +21,5 @@ run B --gaussians 1000000 --width 1920 --height 1080 --scene S --frames 300
 run C --gaussians 6000000 --width 1920 --height 1080 --scene S --frames 100
 run T --gaussians 6000000 --width 1920 --height 1080 --scene T --frames 100
 run E --gaussians 6000000 --width 3840 --height 2160 --scene S --frames 60
-cat "$LOG"
+sed -E "s/\(min.*bit-equal/bit-equal/; s/ V [0-9]+ E1.*spans us/ spans/" "$LOG"
 timeout 240 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3
