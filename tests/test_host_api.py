@@ -186,3 +186,29 @@ def test_parallel_activation_matches_serial(pkg, oracle):
     b = np.concatenate([pkg.activate_records(rec[i:i + 10_000]) for i in range(0, len(rec), 10_000)])
     np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
     np.testing.assert_array_equal(a[:2000].view(np.uint32), oracle.activate_records(rec[:2000]).view(np.float32).reshape(-1, 60).view(np.uint32))
+
+
+def test_dense_list_geometry_holds_what_its_workgroups_append(pkg):
+    """k_preprocess's workgroup b (256 Gaussians) appends its visible ones to list b % 256 (gs_kernels.h, AttrView::vis).
+    A list must hold ALL Gaussians of its workgroups (every one may be visible), be a whole number of level-1 blocks
+    (1024 slots), and the level-1 table must have a column for every block of either input (planes or lists).
+    Pure host functions of the library: no GPU needed."""
+    L = pkg.binding.lib()
+    slots_of = getattr(L, "_ZN2gs16vis_region_slotsEj")
+    columns_of = getattr(L, "_ZN2gs18bin_level1_columnsEj")
+    blocks_of = getattr(L, "_ZN2gs17bin_level1_blocksEj")
+    for f in (slots_of, columns_of, blocks_of):
+        f.restype = ctypes.c_uint32
+        f.argtypes = [ctypes.c_uint32]
+    rng = np.random.default_rng(0)
+    sizes = [0, 1, 255, 256, 257, 65535, 65536, 65537, 10_000, 1_000_000, 6_000_000, 2**24, 2**24 + 1, 100_000_000, 2**31 - 1]
+    sizes += [int(x) for x in rng.integers(1, 2**28, 200)]
+    for n in sizes:
+        slots = slots_of(n)
+        groups = -(-n // 256)
+        fullest = -(-groups // 256) * 256  # Gaussians of the workgroups 0, 256, 512, ... (list 0 has the most)
+        assert slots >= max(fullest, 1) and slots % 1024 == 0, (n, slots)
+        assert slots - fullest < 1024 or n == 0, (n, slots)  # ... and no more than the rounding (an empty scene: one block)
+        assert columns_of(n) >= 256 * (slots // 1024) and columns_of(n) >= blocks_of(n), n
+        assert 256 * slots * 16 <= 2**40  # 1 TiB: the list index stays far inside 32 bits of slots
+        assert 256 * slots < 2**32, n
