@@ -603,8 +603,9 @@ struct gs_renderer {
     // GS_L1_DENSE_MIN: scenes of at least this many Gaussians hand level 1 the dense lists of visible Gaussians (measured
     // A/B, profiles/r03_l1_dense_lists_ab.txt: 6 M Gaussians +2 % one frame at a time, +2..7 % with three in flight --
     // level 1 is several rounds of workgroups there; 1 M: -0.5 %, level 1 is one round of workgroups bound by its round
-    // trips and k_preprocess pays 2 us for the lists).  The GPU tests set it to 0 for small scenes.
-    uint64_t dense_min = 2u << 20;
+    // trips and k_preprocess pays 2 us for the lists; 2 M and 3.5 M, profiles/r03_l1_dense_threshold.txt: -2.2 % / -0.5 %
+    // one frame at a time, +0.5 % with three in flight).  The GPU tests set it to 0 for small scenes.
+    uint64_t dense_min = 4u << 20;
     bool refined = false;        // bins of half that edge: taken when a bin outgrows the largest in-LDS order
     bool have_frame = false;
     uint32_t retries = 0;        // lifetime count of re-run frames (statistics only)

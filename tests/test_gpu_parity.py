@@ -103,7 +103,7 @@ def test_rotated_translated_camera(pkg, oracle, gpu):
 @pytest.mark.parametrize("dense_min", ["0", "1000000000"])
 def test_level1_over_the_dense_lists_and_over_the_planes(pkg, oracle, gpu, monkeypatch, dense_min):
     """Level 1 of the bin-local path takes its items from the dense lists of visible Gaussians k_preprocess appends to
-    (scenes of >= GS_L1_DENSE_MIN Gaussians; default 2 M, so the small scenes of this file would never use them) or from the
+    (scenes of >= GS_L1_DENSE_MIN Gaussians; default 4 M, so the small scenes of this file would never use them) or from the
     N-wide planes.  Both forced here on the same scenes: stages and pixels equal the oracle's; the lists' counters are
     zeroed by each frame's last kernel, so frame after frame on the same buffers -- serial, four in flight, after an
     overflow re-run, after a resolution change -- must stay equal."""
