@@ -22,6 +22,11 @@ RECORD_FLOATS = 62
 BLOB_PLANES = 59
 
 
+# the device code of libgs3d_hip.so: one translation unit per stage + the shared device headers
+KERNEL_SOURCES = ("gs_device.h", "gs_bin.h", "gs_scene.hip", "gs_preprocess.hip", "gs_radix.hip", "gs_bin_l1.hip", "gs_bin_l2.hip",
+                  "gs_blend.hip", "gs_kernels.h")
+
+
 def library_source_hash():
     """sha256 over the KERNEL sources (comments and whitespace stripped) and the build flags libgs3d_hip.so is built from:
     ties a committed rocprofv3 counter file to the kernels it was collected on (bench.py refuses counters of other
@@ -29,7 +34,7 @@ def library_source_hash():
     import hashlib
     import re
     h = hashlib.sha256()
-    for name in ("gs_kernels.hip", "gs_kernels.h", "Makefile"):
+    for name in KERNEL_SOURCES + ("Makefile",):
         with open(os.path.join(_HERE, "csrc", name), "r") as f:
             text = f.read()
         if name != "Makefile":

@@ -1,4 +1,4 @@
-// gs_kernels.h -- launch wrappers of the gfx950 kernels (gs_kernels.hip).
+// gs_kernels.h -- launch wrappers of the gfx950 kernels (gs_scene / gs_preprocess / gs_radix / gs_bin_l1 / gs_bin_l2 / gs_blend .hip).
 // Host-side declarations only; everything takes raw device pointers + a stream.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -120,7 +120,7 @@ struct RadixPass {
 };
 void launch_radix_pass(const RadixPass& p, hipStream_t s);
 
-// Two-level binning (gs_kernels.hip): level 1 lists the items (Gaussians in index order, or the visible Gaussians in
+// Two-level binning (gs_bin_l1.hip, gs_bin_l2.hip): level 1 lists the items (Gaussians in index order, or the visible Gaussians in
 // depth order when `order` is given) per bin of S x S tiles; level 2 turns each bin's list into the per-tile lists
 // (ordering it by (depth bits, id) in LDS first when sort is set), the tile ranges and D.
 struct BinLaunch {

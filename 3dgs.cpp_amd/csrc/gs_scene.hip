@@ -1,0 +1,67 @@
+// gs_scene.hip -- load-time kernels: cov3D precompute, SH quantisation.
+//
+// Part of libgs3d_hip.so (gfx950 only).  Built with -ffp-contract=off: the floating-point contract of this path is "IEEE
+// binary32, one rounding per operation, in the order the reference shader writes it" (DESIGN.md section 3); fused
+// multiply-adds appear only where written explicitly.
+// Reference restated (paths relative to /root/reference/src/shaders): precomp_cov3d.comp:25-47, common.glsl:51-75
+#include "gs_device.h"
+
+namespace gs {
+
+// ---------------------------------------------------------------------------------------
+// cov3D precompute (load time).  precomp_cov3d.comp:25-47.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ M3 rotation_from_quaternion(float qw, float qx, float qy, float qz) {
+    float qx2 = qx * qx, qy2 = qy * qy, qz2 = qz * qz;
+    M3 m;
+    m.c[0][0] = 1 - 2 * qy2 - 2 * qz2;
+    m.c[0][1] = 2 * qx * qy - 2 * qz * qw;
+    m.c[0][2] = 2 * qx * qz + 2 * qy * qw;
+    m.c[1][0] = 2 * qx * qy + 2 * qz * qw;
+    m.c[1][1] = 1 - 2 * qx2 - 2 * qz2;
+    m.c[1][2] = 2 * qy * qz - 2 * qx * qw;
+    m.c[2][0] = 2 * qx * qz - 2 * qy * qw;
+    m.c[2][1] = 2 * qy * qz + 2 * qx * qw;
+    m.c[2][2] = 1 - 2 * qx2 - 2 * qy2;
+    return m;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cov3d(const float* __restrict__ blob, float* __restrict__ cov3d,
+                                                 uint32_t n, uint32_t stride) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = stride, NC = n;
+    const float scale_factor = 1.0f;  // GSScene.cpp:176
+    M3 S = {};
+    S.c[0][0] = blob[(P_SCALE + 0) * N + i] * scale_factor;
+    S.c[1][1] = blob[(P_SCALE + 1) * N + i] * scale_factor;
+    S.c[2][2] = blob[(P_SCALE + 2) * N + i] * scale_factor;
+    M3 R = rotation_from_quaternion(blob[(P_ROT + 0) * N + i], blob[(P_ROT + 1) * N + i],
+                                    blob[(P_ROT + 2) * N + i], blob[(P_ROT + 3) * N + i]);
+    M3 M = m3_mul(S, R);
+    M3 C = m3_mul(m3_transpose(M), M);
+    cov3d[0 * NC + i] = C.c[0][0];
+    cov3d[1 * NC + i] = C.c[0][1];
+    cov3d[2 * NC + i] = C.c[0][2];
+    cov3d[3 * NC + i] = C.c[1][1];
+    cov3d[4 * NC + i] = C.c[1][2];
+    cov3d[5 * NC + i] = C.c[2][2];
+}
+
+// Opt-in SH quantisation: the fp32 SH block -> binary16, round to nearest even.
+__global__ __launch_bounds__(BLOCK) void k_sh_to_half(const float* __restrict__ sh, uint16_t* __restrict__ out, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < count) out[i] = __half_as_ushort(__float2half_rn(sh[i]));
+}
+void launch_sh_to_half(const float* blob, uint16_t* sh16, uint32_t n, uint32_t stride, hipStream_t s) {
+    if (n == 0) return;
+    const uint64_t count = 48ull * n;
+    hipLaunchKernelGGL(k_sh_to_half, dim3((uint32_t)((count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                       blob + (size_t)P_SH * stride, sh16, count);
+}
+
+void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_cov3d, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob, cov3d, n, stride);
+}
+}  // namespace gs

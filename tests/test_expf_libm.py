@@ -28,7 +28,7 @@ def test_equal_to_libm_on_every_nonpositive_binary32(oracle):
 
 def test_the_kernels_operation_sequence_equals_libm_too(oracle):
     """The HIP blend evaluates the same cubic times the same table value in four binary64 operations instead of glibc's
-    five (gs_expf_libm in gs_kernels.hip; gso_expf_device restates exactly that sequence).  IEEE binary64 arithmetic
+    five (gs_expf_libm in gs_blend.hip; gso_expf_device restates exactly that sequence).  IEEE binary64 arithmetic
     gives the same bits on the host as on the device, so its equality with libm on every input the blend can ask for is
     decided here, exhaustively -- and re-checked end to end by the GPU tests, where the frame must equal the reference
     text's bit for bit."""
