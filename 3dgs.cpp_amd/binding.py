@@ -48,7 +48,7 @@ def library_source_hash():
 
 STAGES = dict(tiles=(0, np.uint32), depth=(1, np.float32), radius=(2, np.float32), aabb=(3, np.uint16),
               conic_opacity=(4, np.float32), uv_rg=(5, np.float32), b=(6, np.float32),
-              depth_order=(7, np.uint32), sorted_tile=(11, np.uint32), sorted_gid=(12, np.uint32),
+              depth_order=(7, np.uint32), alpha_cut=(8, np.float32), sorted_tile=(11, np.uint32), sorted_gid=(12, np.uint32),
               ranges=(13, np.uint32), lists_raw=(14, np.uint32), ranges_raw=(15, np.uint32))
 
 # every symbol include/gs3d_hip.h declares
@@ -58,7 +58,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
            "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_set_blend_contraction", "gs_get_timing_totals",
-           "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_renderer_stream",
+           "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_debug_expf_scan", "gs_renderer_stream",
            "gs_dist_unique_id", "gs_dist_create", "gs_dist_rank", "gs_dist_world", "gs_dist_pose_count",
            "gs_dist_broadcast_scene", "gs_dist_broadcast_scene_ex", "gs_dist_destroy"]
 
@@ -69,10 +69,19 @@ class FrameStats(C.Structure):
                 ("ms_preprocess_sort", C.c_float), ("ms_sort", C.c_float), ("ms_tile_boundary", C.c_float),
                 ("ms_render", C.c_float), ("ms_total", C.c_float), ("retries", C.c_uint32),
                 ("num_bin_entries", C.c_uint32), ("max_bin_entries", C.c_uint32), ("sort_path", C.c_uint32),
-                ("bin_tiles", C.c_uint32), ("sort_level", C.c_uint32), ("pad_", C.c_uint32)]
+                ("bin_tiles", C.c_uint32), ("sort_level", C.c_uint32), ("blend_redo", C.c_uint32), ("blend_resolved", C.c_uint32), ("pad_", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def debug_expf_scan(first_bits, count, device=0):
+    """Test hook gs_debug_expf_scan: (block checksums of the kernels' expf over the bit patterns, the guard's measured premise)."""
+    blocks = (count + (1 << 20) - 1) >> 20
+    sums = np.zeros(blocks, np.uint64)
+    guard = np.zeros(4, np.float64)
+    _check(lib().gs_debug_expf_scan(C.c_int(device), C.c_uint32(first_bits), C.c_uint64(count), _p(sums), C.c_uint64(blocks), _p(guard)))
+    return sums, guard
 
 
 class GsError(RuntimeError):
@@ -263,7 +272,8 @@ class Renderer:
         _check(lib().gs_set_frames_in_flight(self._h, C.c_int(int(frames))))
 
     def set_exp_mode(self, mode):
-        """2 (default) libm's expf restated in binary64, 0 pipeline-defined polynomial, 1 hardware v_exp_f32 (gs_set_exp_mode)."""
+        """3 (default) v_exp_f32 under the guard of render.comp:82 (the reference's decisions, its pixels to rounding noise), 2 libm's expf
+        restated in binary64 (the reference's bits), 0 pipeline-defined polynomial, 1 v_exp_f32 unguarded (gs_set_exp_mode)."""
         _check(lib().gs_set_exp_mode(self._h, C.c_int(int(mode))))
 
     def set_blend_contraction(self, enabled):
@@ -271,7 +281,7 @@ class Renderer:
         _check(lib().gs_set_blend_contraction(self._h, C.c_int(int(bool(enabled)))))
 
     def set_fast_blend(self, fast):
-        """True: both opt-in relaxations (polynomial exp, contractions); False: the default, bit-identical to the reference text."""
+        """True: both opt-in relaxations (polynomial exp, contractions); False: exp mode 2 as written, bit-identical to the reference text."""
         self.set_exp_mode(0 if fast else 2)
         self.set_blend_contraction(bool(fast))
 
@@ -308,7 +318,7 @@ class Renderer:
         st = self.stats()
         n, v, d = st.num_gaussians, st.num_visible, min(st.num_instances, st.instance_capacity)
         count = {"tiles": n, "depth": n, "radius": n, "aabb": 4 * n, "conic_opacity": 4 * n, "uv_rg": 4 * n,
-                 "b": n, "depth_order": v, "sorted_tile": d, "sorted_gid": d, "lists_raw": d}.get(name)
+                 "b": n, "alpha_cut": n, "depth_order": v, "sorted_tile": d, "sorted_gid": d, "lists_raw": d}.get(name)
         if name in ("ranges", "ranges_raw"):
             w, h = int(uniforms["width"][0]), int(uniforms["height"][0])
             count = 2 * ((w + 15) // 16) * ((h + 15) // 16)

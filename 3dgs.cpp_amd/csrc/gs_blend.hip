@@ -18,23 +18,30 @@ namespace gs {
 // saturated retires at once and a slow quadrant never stalls its neighbours.
 //
 // Each wave walks its tile's depth-sorted list in chunks of 64 entries: lane l fetches entry l's record
-// (9 floats, gathered through the sorted Gaussian id; the next chunk is prefetched while the current one
+// (one 64-byte line, gathered through the sorted Gaussian id; the next chunk is prefetched while the current one
 // is blended), tests it against the wave's quadrant, parks it in a wave-private LDS slab, and a 64-bit
 // ballot of the survivors drives a scalar loop that evaluates only those entries, in list order, with
-// broadcast LDS reads.  The per-pixel body is predicated (selects) instead of branched: nested divergent
-// branches cost ~40 scalar exec-mask instructions per entry and saturate the CU's scalar unit.
+// broadcast LDS reads.  Pixel predicates live in 64-bit scalar masks; the accumulate runs under the exec mask.
 //
-// render.comp:61-98 semantics.  Floating-point contract: the shader's expressions with the three
-// multiply-adds that GLSL lets a compiler contract written as explicit FMAs (marked FMA below; the
-// oracle makes the same choice), nothing reassociated.
+// render.comp:61-98 semantics.  Floating-point contract of the DEFAULT arithmetic (CONTRACT = false): every product and
+// sum of :66 and :87 rounded on its own, in the order the shader writes them -- what the reference's text compiled for the
+// CPU evaluates.  CONTRACT = true: the three multiply-adds GLSL lets a compiler contract, written as explicit FMAs (opt-in).
 //
-// Exactness of the culling: an entry contributes to a pixel only if alpha = min(0.99, o*exp(power))
-// >= 1/255, i.e. power >= -tau with tau = ln(255*o), and -power = q(d) = 0.5 d^T C d (C = conic) is
-// a convex quadratic of d = uv - pixel.  If the minimum of q over the quadrant's pixel rectangle exceeds
-// tau (with 0.1 % + 1e-3 slack against the rounding of exp/log, plus 8 ULP of the quadratic's largest TERMS over the
-// quadrant against the cancellation error of `power` for thin diagonal splats), every pixel of the
-// quadrant executes `continue` in the shader, so skipping the entry for that wave changes nothing.
-// The same bound gives a per-entry lower limit on power below which exp() need not be evaluated.
+// The two data-dependent cuts of the loop, and why no exp mode can flip the first:
+//   :78  `if (alpha < 1/255) continue`  is decided on `power`, against the entry's ALPHA CUT (gs_device.h: alpha_cut; a
+//        function of the opacity, computed at load, carried in the record): power >= cut  <=>  the reference's alpha, with
+//        libm's expf, is >= 1/255 -- bit for bit, by monotonicity.  Lanes below the cut never evaluate exp.
+//   :82  `if (T (1 - alpha) < 1e-4) break`  depends on the accumulated T.  With EXP = 2 (libm's expf restated) alpha and T are
+//        the reference's own bits.  With a fast exp they drift by a few ULP per step; GUARD = true makes the decision safe:
+//        a wave in which a pixel's T (1 - alpha) comes within a PROVEN window of 1e-4 (blend_walk, kGuard*) abandons its
+//        fast pass and re-renders its quadrant with EXP = 2.  Everything that is not re-rendered has taken exactly the
+//        reference's decisions and differs from it by rounding noise only.
+//
+// Exactness of the culling: an entry contributes to a pixel only if power >= cut, and -power = q(d) = 0.5 d^T C d
+// (C = conic) is a convex quadratic of d = uv - pixel.  If the minimum of q over the quadrant's pixel rectangle exceeds
+// -cut (plus 16 ULP of the quadratic's largest TERMS over the quadrant, against the cancellation error of `power` and of
+// the bound itself for thin diagonal splats), every pixel of the quadrant executes `continue` in the shader, so skipping
+// the entry for that wave changes nothing.
 // ---------------------------------------------------------------------------------------
 
 // min over the pixel rectangle [xa,xb] x [ya,yb] of q(d) = 0.5 (c00 dx^2 + c11 dy^2) + c01 dx dy,
@@ -59,7 +66,7 @@ __device__ __forceinline__ float min_q_rect(float c00, float c01, float c11, flo
     const float qh = __builtin_fmaf(s, __builtin_fmaf(h00, s, c01 * b), h11 * b * b);
     // The cull `mq > lim` needs mq to be a LOWER bound of q over the quadrant, and evaluating the parabola at an inexact
     // minimiser (v_rcp_f32: 1 ULP) OVER-estimates its minimum -- by a second-order amount: q(t* + dt) - q(t*) = h dt^2 with
-    // dt/t* ~ 2^-23, i.e. ~1e-14 relative, which the caller's slack (4.8e-7 x the quadratic's largest terms + 0.1 %) absorbs
+    // dt/t* ~ 2^-23, i.e. ~1e-14 relative, which the caller's slack (9.6e-7 x the quadratic's largest terms) absorbs
     // many times over.  A coarser reciprocal or a smaller slack must revisit this.
     return in_x ? (in_y ? 0.0f : qh) : (in_y ? qv : fminf(qv, qh));
 }
@@ -72,96 +79,333 @@ __device__ unsigned long long g_blend_stats[12];
 #define STAT_ADD(i, v) do { } while (0)
 #endif
 
-// gs_exp without the lower clamp: every lane whose result is used has power in [-7, 0].
-__device__ __forceinline__ float gs_exp_blend(float x) {
-    const float L2E = 1.44269502162933349609375f;
-    const float MAGIC = 12582912.0f;
-    float tm = __builtin_fmaf(x, L2E, MAGIC);
-    float n = tm - MAGIC;
-    float f = __builtin_fmaf(x, L2E, -n);
-    float p = 0x1.41d332p-13f;
-    p = __builtin_fmaf(p, f, 0x1.5f456ap-10f);
-    p = __builtin_fmaf(p, f, 0x1.3b2dbcp-7f);
-    p = __builtin_fmaf(p, f, 0x1.c6aed4p-5f);
-    p = __builtin_fmaf(p, f, 0x1.ebfbdap-3f);
-    p = __builtin_fmaf(p, f, 0x1.62e430p-1f);
-    p = __builtin_fmaf(p, f, 1.0f);
-    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(tm) << 23));
-}
-
-// exp() as glibc's expf evaluates it (glibc >= 2.27, sysdeps/ieee754/flt-32/e_expf.c = ARM optimized-routines expf: x 32/ln2 split
-// into k + r in binary64, 2^(k/32) from a 32-entry table, a cubic in r, ONE rounding to binary32 at the end), operation by
-// operation in binary64 with the fused operations of the x86-64 FMA build -- so that the blend can be bit-identical to the
-// reference's shader text compiled for the CPU (the test suite's checker), whose exp() is libm's.  Restated from the published algorithm,
-// the table generated (2^(i/32) correctly rounded, exponent pre-subtracted), and PINNED by tests/test_expf_libm.py: equal to
-// this container's libm expf on every binary32 <= 0 (2.1e9 values).  9 binary64 operations (half rate on gfx950) + one
-// LDS read: ~23 issue slots against 10 for the polynomial.  Valid for the blend's range (x <= 0, results used for x >= -7).
-__device__ const uint64_t kExpfTab[32] = {
-    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
-    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
-    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
-    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
-    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
-    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
-    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
-__device__ __forceinline__ float gs_expf_libm(float x, const uint2* __restrict__ tab /* LDS copy of kExpfTab */) {
-    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
-    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0, C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
-    const double xd = (double)x;
-    double kd = __builtin_fma(InvLn2N, xd, SHIFT);          // k = round(x 32/ln2) in the low mantissa bits
-    const uint32_t ki = (uint32_t)__double_as_longlong(kd);
-    kd = kd - SHIFT;
-    const double r = __builtin_fma(InvLn2N, xd, -kd);
-    uint2 t = tab[ki & 31u];
-    t.y += ki << 15;                                        // t += ki << 47: the exponent of 2^(k/32)
-    const double sc = __longlong_as_double((long long)(((uint64_t)t.y << 32) | t.x));
-    // glibc evaluates  z = C0 r + C1;  y = C2 r + 1;  y = z r^2 + y;  y = y s  (five operations).  Here the same cubic times the
-    // same s in four:  q = (C0 r + C1) r + C2;  y = q (r s) + s.  The two differ in the last bits of the binary64 value, never
-    // in its rounding to binary32: tests/test_expf_libm.py runs this very sequence against libm's expf on every binary32 <= 0
-    // (IEEE binary64 operations give the same bits on the host as on the device).  q's first fma is written as one VOP3
-    // v_fma_f64 (left to itself the compiler copies C1 and uses the two-address v_fmac_f64).
-    double q0, q;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q0) : "s"(C0), "v"(r), "v"(C1));
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(q0), "v"(r), "v"(C2));
-    const double rs = r * sc;
-    const double y = __builtin_fma(q, rs, sc);
-    return (float)y;
-}
-
 struct BlendEntry {
     float4 co;  // c00 c01 c11 opacity
     float4 uv;  // u v r g
-    float b;
+    float2 bc;  // b, alpha cut
 };
 
 __device__ __forceinline__ void blend_fetch(BlendEntry& e, uint32_t g, const AttrRecord* __restrict__ rec) {
     const AttrRecord* r = rec + g;  // one 64-byte line
     e.co = r->conic_op;
     e.uv = r->uv_rg;
-    e.b = r->b_depth_r.x;
+    const float4 t = r->b_depth_r;
+    e.bc = make_float2(t.x, t.w);
 }
 
-// CONTRACT: the pipeline's three contractions of render.comp:66,87 (default) or the uncontracted reading, one rounding per
-// operation exactly as the shader is written -- what the reference's text compiled for the CPU evaluates (gs_set_blend_contraction).
+// ---- the guard of render.comp:82-85 for a fast exp (GUARD) ---------------------------------------------------------
+// Let a' = fl(o e') be the fast alpha (e' = v_exp_f32(fl(power log2e))) and a = fl(o e) the reference's (e = libm's expf).
+// tests/test_gpu_expf.py scans every binary32 power in [-16, 0] ON THE DEVICE and asserts |e' - e| <= (E0e + E1 |power|) e;
+// the two roundings of the product add 2^-23:  |a' - a| <= (kGuardE0 + kGuardE1 |power|) a,  kGuardE0 = E0e + 2^-23.
+// One step  T <- fl(T fl(1 - alpha)):  the two chains' (1 - alpha) differ by |a' - a| plus one ULP, the products by one more
+// ULP, so the relative distance of the chains grows per step by at most
+//      a / (1 - a) (kGuardE0 + kGuardE1 |power|)  +  2^-22.
+// With o <= 1, |power| <= ln(1/a) and a/(1 - a) ln(1/a) <= 1, so after n steps
+//      |T'(1 - a') - T(1 - a)|  <=  W T(1 - a),      W = S kGuardE0 + n (kGuardE1 + 2^-22),   S = sum a_i / (1 - a_i)
+// (n <= the (entry, wave) pairs evaluated so far, a scalar count).  S has two bounds:
+//   * for any pixel S <= 297: while no break was taken prod (1 - a_i) >= 1e-4, and a/(1 - a) <= 21.5 (-ln(1 - a)) for a <= 0.99,
+//     i.e. <= 198; the tested step adds <= 99.  With n <= kGuardMaxPairs this gives the COARSE window, two constants;
+//   * per lane: over any run of steps  sum a_i/(1 - a_i) <= prod (1 + a_i/(1 - a_i)) - 1 = T_before / T_after - 1,  so a lane
+//     that adds T_chunk_start / T_chunk_end - 1 to a running sum at every chunk end (one v_rcp per 64 entries) carries a bound
+//     that is a few units for ordinary pixels (a dozen chunks, T falling by a factor of two or three in each).  This gives
+//     the lane's OWN window, evaluated only for lanes inside the coarse one.
+// A lane whose fast T(1 - alpha) lies outside [1e-4 (1 - W), 1e-4 (1 + W)) takes the reference's decision.  For a lane inside
+// its own window, the reference's decision is COMPUTED:
+// resolve_break replays that one pixel's list with the reference's arithmetic (64 entries per step across the lanes, libm's
+// expf, then the chain of fl(T fl(1 - alpha)) products in list order) and returns what render.comp:83 sees.  A quadrant that
+// needs more than kGuardMaxResolves of those, or one beyond the kGuardList entries its list of kept entries holds, is abandoned and re-rendered whole
+// with EXP = 2.  (A scene holding an opacity > 1 -- outside the sigmoid's range, where |power| is not bounded by ln(1/a) -- is
+// blended with EXP = 2 altogether: launch_blend's `unit_opacity`.)  The constants carry 5 % head-room for the
+// second-order terms and the rounding of the thresholds themselves.
+constexpr float kGuardE0 = 2.0e-7f, kGuardE1 = 8.0e-8f;  // measured on the device: E0e = 6.9e-8 (+ 2^-23 = 1.88e-7) with this E1
+#ifndef GS_GUARD_SCALE
+#define GS_GUARD_SCALE 1.0f  // experiments only (tools/r04_guard.py): the window scaled; below 1 the guarantee is gone
+#endif
+constexpr float kGuardUnit = GS_GUARD_SCALE * 1.05f * kGuardE0, kGuardBase = 297.0f * kGuardUnit, kGuardStep = GS_GUARD_SCALE * 1.05f * (kGuardE1 + 2.3841858e-7f);
+constexpr float kGuardSMax = 297.0f;
+constexpr uint32_t kGuardMaxResolves = 8, kGuardMaxPairs = 4096;
+constexpr uint32_t kGuardList = 384;  // entries of a wave's list of kept entries (LDS, 1.5 KiB per wave: 19 KiB per workgroup, eight per CU)
+// the coarse window, constant: S <= 297, n <= kGuardMaxPairs (a quadrant that keeps more entries is abandoned)
+constexpr float kGuardCoarse = kGuardBase + (float)kGuardMaxPairs * kGuardStep;
+constexpr float kGuardHi = 0.0001f * (1.0f + kGuardCoarse), kGuardLo = 0.0001f * (1.0f - kGuardCoarse);
+// What the guard adds to EVERY pair is one compare: beside render.comp:83's own, an SDWA compare of the upper half of
+// T (1 - alpha)'s bit pattern with 0x38D1 (1e-4 is 0x38D1B717): equal <=> the value lies in the slice [9.96590e-5, 1.004364e-4),
+// 0.8 % wide, which contains the coarse window.  3 % of the pairs have a lane in the slice and go on to the window tests.
+// (Measured alternatives, config B, serial blend: a second compare at break events only -- 40 % of the pairs have one -- 0.193 ms
+// without any replay against 0.181 ms for this form and 0.178 ms for the unguarded loop.)
+constexpr uint32_t kGuardSlice = 0x38D1u;
+static_assert(kGuardHi < 1.0043e-4f && kGuardLo > 9.966e-5f, "the coarse window must lie inside the slice");
+
+// render.comp:83 for ONE pixel (fxa, fya) at the entry in position `pos` of the wave's list of kept entries, as the reference
+// evaluates it: is T (1 - alpha) < 1e-4 there?  Premise (the guard's induction): no earlier entry made this pixel break.
+// klist: the tile-list indices of the entries the quadrant's exact culling kept, in list order (what it dropped is skipped by
+// every pixel of the quadrant, so the pixel's chain runs over these alone).  Every lane takes one entry per step -- two or
+// three steps for an ordinary quadrant; the arithmetic is the pair loop's with EXP = 2 (the pre-scaled conic, the alpha cut,
+// libm's expf); the T chain runs over the kept entries in list order through v_readlane.  All 64 lanes are active, every
+// value that matters is wave-uniform, and no load is in flight when this returns (the caller's pair loop keeps the next
+// chunk's prefetch outstanding: a possibly-pending load on its back-edge would make the compiler wait at every pair).
+__device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist, const uint32_t pos,
+                                              const uint32_t* __restrict__ sorted_gid, const AttrRecord* __restrict__ rec,
+                                              const uint2* __restrict__ exptab, const int lane, const float fxa, const float fya) {
+#ifdef GS_GUARD_STUB  // experiment: the replay compiled out (wrong decisions; timing only)
+    return false;
+#endif
+    float T = 1.0f;
+    bool brk = false;
+    for (uint32_t p0 = 0; p0 <= pos; p0 += WAVE) {
+        const uint32_t p = p0 + (uint32_t)lane;
+        float4 co = make_float4(0, 0, 0, 0);
+        float2 uv = make_float2(0, 0);
+        float cut = __uint_as_float(0x7F800000u);
+        if (p <= pos) {
+            const AttrRecord* r = rec + sorted_gid[klist[p]];
+            co = r->conic_op;
+            uv = make_float2(r->uv_rg.x, r->uv_rg.y);
+            cut = r->b_depth_r.w;
+        }
+        const float dx = uv.x - fxa, dy = uv.y - fya;
+        const float cx = -0.5f * co.x, cy = -co.y, cz = -0.5f * co.z;
+        const float s = cx * dx * dx + cz * dy * dy;
+        const float power = s + cy * dx * dy;
+        const bool kept = power <= 0.0f && !(power < cut);  // (cut = +inf past pos)
+        const float alpha = fminf(0.99f, co.w * gs_expf_libm(power, exptab));
+        const float oma = 1 - alpha;
+        uint64_t m = __ballot(kept);
+        while (m) {
+            const int j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const float f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(oma), j));
+            const float test_T = T * f;
+            if (p0 + (uint32_t)j == pos) brk = test_T < 0.0001f;
+            else T = test_T;
+        }
+    }
+    return brk;
+}
+
+// One pass of a wave over its tile's list: returns false if the quadrant has to be re-rendered exactly (GUARD only; c0..c2
+// are then meaningless).  slab: this wave's three planes of 64 float4 {c00' c01' c11' o} {u v r g} {b, cut, -, -} --
+// plane-major keeps the staging ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets
+// serve the broadcast reads.  resolved: GUARD, how many break decisions resolve_break took.
 // EXP: 0 the pipeline-defined polynomial (gs_exp_blend), 1 the hardware's v_exp_f32, 2 libm's expf restated (gs_expf_libm).
-template <int EXP, bool CONTRACT>
-__global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ ranges,
+template <int EXP, bool CONTRACT, bool GUARD>
+__device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __restrict__ sorted_gid,
+                                           const AttrRecord* __restrict__ rec, float4 (*__restrict__ slab)[WAVE],
+                                           uint2* __restrict__ exptab_rw, uint32_t* __restrict__ klist, const int lane, const float fx, const float fy,
+                                           const float rx0, const float ry0, uint64_t alive, float& c0, float& c1, float& c2,
+                                           uint32_t& resolved, bool& table_ready) {
+    const uint2* __restrict__ exptab = exptab_rw;
+    float T = 1.0f;
+    c0 = c1 = c2 = 0.0f;
+    uint32_t npairs = 0;                       // GUARD: (entry, wave) pairs evaluated so far (bounds every lane's step count)
+    bool abandon = false;                      // GUARD: re-render the quadrant exactly
+    float S = 0.0f, T_cs = 1.0f;               // GUARD: the lane's bound on sum a/(1 - a) over the finished chunks; T at the chunk's start
+    resolved = 0;
+    // software pipeline over 64-entry chunks: ids two chunks ahead, records one chunk ahead
+    BlendEntry nxt;
+    nxt.co = make_float4(0, 0, 0, 0);
+    nxt.uv = make_float4(0, 0, 0, 0);
+    nxt.bc = make_float2(0, 0);
+    uint32_t g_next = 0;
+    {
+        const uint32_t i0 = range.x + lane;
+        if (i0 < range.y) blend_fetch(nxt, sorted_gid[i0], rec);
+        const uint32_t i1 = i0 + WAVE;
+        if (i1 < range.y) g_next = sorted_gid[i1];
+    }
+    for (uint32_t base = range.x; base < range.y; base += WAVE) {
+        const BlendEntry cur = nxt;
+        const bool have = base + lane < range.y;
+        {   // prefetch: records of chunk +1 (ids already here), ids of chunk +2
+            const uint32_t i1 = base + WAVE + lane;
+            if (i1 < range.y) blend_fetch(nxt, g_next, rec);
+            const uint32_t i2 = i1 + WAVE;
+            if (i2 < range.y) g_next = sorted_gid[i2];
+        }
+        // classify entry `lane` of this chunk against the wave's quadrant.  cut = +inf: no power <= 0 is kept (never
+        // enters); -inf (NaN or infinite opacity: min(0.99, NaN) is 0.99 in the pipeline's definition): never culled
+        const float cut = cur.bc.y;
+        bool keep = have && cut <= 0.0f;
+        if (keep) {
+            const float mq = min_q_rect(cur.co.x, cur.co.y, cur.co.z, cur.uv.x, cur.uv.y, rx0, rx0 + 7.0f, ry0, ry0 + 7.0f);
+            // The rounding error of the shader's `power` (and of mq) is relative to the TERMS c00 dx^2, c11 dy^2,
+            // c01 dx dy, not to their sum: a thin diagonal splat far from its centre has terms ~1e5 cancelling to
+            // q ~ 5.  The slack therefore grows with the terms at the quadrant's corner farthest from the centre
+            // (16 roundings of 2^-24 each, generously).
+            const float ax = fmaxf(fabsf(cur.uv.x - rx0), fabsf(cur.uv.x - (rx0 + 7.0f)));
+            const float ay = fmaxf(fabsf(cur.uv.y - ry0), fabsf(cur.uv.y - (ry0 + 7.0f)));
+            const float mag = __builtin_fmaf(0.5f * fabsf(cur.co.x) * ax, ax,
+                                             __builtin_fmaf(0.5f * fabsf(cur.co.z) * ay, ay, fabsf(cur.co.y) * ax * ay));
+            keep = !(mq > __builtin_fmaf(mag, 9.6e-7f, -cut));  // NaN -> keep
+        }
+        uint64_t bm = __ballot(keep);
+        STAT_ADD(0, 1);
+        STAT_ADD(6, __popcll(__ballot(have)));
+        STAT_ADD(1, __popcll(bm));
+        if (bm == 0) continue;
+        const uint64_t bm0 = bm;      // GUARD: the chunk's kept entries (bm is consumed below)
+        const uint32_t kbase = npairs;  // GUARD: how many entries the list of kept entries held before this chunk
+        if (GUARD) {
+            // abandon: set where a break decision had to be resolved (see there); more pairs than the coarse window allows for
+            npairs += (uint32_t)__popcll(bm);
+            if (abandon || npairs > kGuardMaxPairs) {
+                abandon = true;
+                break;
+            }
+            // the wave's list of kept entries, for resolve_break: tile-list index of the chunk's r-th kept entry at kbase + r
+            const uint32_t at = kbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (keep && at < kGuardList) klist[at] = base + (uint32_t)lane;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // conic pre-scaled once per entry: (-c00/2, -c01, -c11/2).  Scaling by a power of two commutes with every
+        // rounding below, so power is bit-identical to render.comp:66 evaluated as written while the per-pixel body
+        // loses the -0.5 multiply
+        slab[0][lane] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
+        slab[1][lane] = cur.uv;
+        slab[2][lane] = make_float4(cur.bc.x, cut, 0.0f, 0.0f);
+
+        while (bm) {
+            const int k = __ffsll((unsigned long long)bm) - 1;
+#if GS_BLEND_SALU_DIET
+            asm("s_bitset0_b64 %0, %1" : "+s"(bm) : "s"(k));  // bm &= bm - 1 costs three scalar instructions
+#else
+            bm &= bm - 1;
+#endif
+            STAT_ADD(2, 1);                       // (entry, wave) pairs evaluated
+            STAT_ADD(3, __popcll(alive));         // lanes alive
+            float4 co = slab[0][k];
+            float4 uv = slab[1][k];
+            float4 bp = slab[2][k];
+            // all ten floats in one LDS round trip: without this the compiler sinks the loads of o, r, g, b
+            // behind the exp() branch, where 94 % of the pairs then pay a second LDS latency
+            asm volatile("" : "+v"(co.w), "+v"(uv.z), "+v"(uv.w), "+v"(bp.x));
+            const float dx = uv.x - fx;
+            const float dy = uv.y - fy;
+            // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
+            float power;
+            if (CONTRACT) {
+                const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);    // FMA  (= -0.5 * the shader's sum)
+                power = __builtin_fmaf(co.y * dx, dy, s);                         // FMA
+            } else {  // -0.5 * (c00 dx dx + c11 dy dy) - c01 dx dy, every product and sum rounded (the conic is pre-scaled)
+                const float s = co.x * dx * dx + co.z * dy * dy;
+                power = s + co.y * dx * dy;
+            }
+            // :68 and :78.  power <= 0 is false for NaN: a NaN power skips the entry (the pipeline's definition);
+            // power >= cut  <=>  alpha >= 1/255 with the reference's exp (the alpha cut)
+            const uint64_t m2 = alive & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                __builtin_amdgcn_ballot_w64(!(power < bp.y));
+            if (m2 != 0) {
+                STAT_ADD(4, 1);                   // pairs reaching exp
+                STAT_ADD(5, __popcll(m2));        // lanes needing exp
+                // :77.  EXP 1: the hardware's v_exp_f32 (what a Vulkan driver emits for exp()); 2: libm's expf, what the
+                // reference's text compiled for the CPU calls; 0: the pipeline-defined polynomial
+                const float ex = EXP == 1   ? __builtin_amdgcn_exp2f(power * 1.44269502162933349609375f)
+                                 : EXP == 2 ? gs_expf_libm(power, exptab)
+                                            : gs_exp_blend(power);
+                const float alpha = fminf(0.99f, co.w * ex);
+                const float test_T = T * (1 - alpha);
+                // :82-85 break
+                uint64_t mk;
+                if (GUARD) {
+                    mk = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                    {
+                        uint64_t eq;  // upper half of the bit pattern == 0x38D1: inside the slice around 1e-4
+                        asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:DWORD" : "=s"(eq) : "v"(test_T), "v"(kGuardSlice));
+                        const uint64_t sl = m2 & eq;
+                        if (sl != 0) {  // (3 % of the pairs)
+                            uint64_t amb = sl & __builtin_amdgcn_ballot_w64(test_T >= kGuardLo && test_T < kGuardHi);  // the coarse window
+                            if (amb != 0) {  // ... and the lane's own?  (S: the finished chunks; T_cs / test_T - 1: this chunk, this step included)
+                                const float S_now = fminf(kGuardSMax, S + __builtin_fmaf(T_cs * 1.00001f, __builtin_amdgcn_rcpf(test_T), -1.0f));
+                                const float W = __builtin_fmaf((float)npairs, kGuardStep, S_now * kGuardUnit);
+                                const bool inside_own = test_T >= __builtin_fmaf(-0.0001f, W, 0.0001f) && test_T < __builtin_fmaf(0.0001f, W, 0.0001f);
+                                amb &= __builtin_amdgcn_ballot_w64(inside_own);
+                            }
+                            if (amb != 0) {  // ask the reference
+                                if (!table_ready) {  // the wave's copy of libm's table, on first use
+                                    if (lane < 32) {
+                                        const uint64_t v = kExpfTab[lane];
+                                        exptab_rw[lane] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+                                    }
+                                    __builtin_amdgcn_wave_barrier();
+                                    table_ready = true;
+                                }
+                                mk &= ~amb;
+                                do {
+                                    const int a = __ffsll((unsigned long long)amb) - 1;
+                                    amb &= amb - 1;
+                                    const float fxa = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fx), a));
+                                    const float fya = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fy), a));
+                                    const uint32_t pos = kbase + (uint32_t)__popcll(bm0 & ((1ull << k) - 1ull));  // the tested entry in the list
+                                    // past the list's end, or one pixel too many: the quadrant is abandoned at the next chunk and
+                                    // re-rendered exactly (necessary / cheaper)
+                                    if (pos >= kGuardList || resolved >= kGuardMaxResolves) abandon = true;
+                                    else if (resolve_break(klist, pos, sorted_gid, rec, exptab, lane, fxa, fya)) mk |= 1ull << a;
+                                    ++resolved;
+                                } while (amb != 0);
+                            }
+                        }
+                    }
+                } else {
+                    mk = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                }
+                STAT_ADD(8, __popcll(m2 & ~mk));   // (pixel, entry) pairs that contribute (alpha >= 1/255, before the break)
+                // the reference's loop walks a pixel's list up to and including the entry it breaks at (render.comp:60-85)
+                STAT_ADD(7, (unsigned long long)__popcll(mk) * ((base - range.x) + (uint32_t)k + 1u));
+                const bool upd = __builtin_amdgcn_inverse_ballot_w64(m2 & ~mk);
+                if (upd) {  // the accumulate runs under the exec mask: no selects
+                    if (CONTRACT) {
+                        c0 = __builtin_fmaf(uv.z * alpha, T, c0);  // :87  FMA
+                        c1 = __builtin_fmaf(uv.w * alpha, T, c1);
+                        c2 = __builtin_fmaf(bp.x * alpha, T, c2);
+                    } else {  // c += color * alpha * T
+                        c0 = c0 + uv.z * alpha * T;
+                        c1 = c1 + uv.w * alpha * T;
+                        c2 = c2 + bp.x * alpha * T;
+                    }
+                    T = test_T;
+                }
+#if GS_BLEND_SALU_DIET
+                // alive &= ~mk, kept opaque: left to itself the compiler turns "did the last pixel just saturate" into
+                // seven scalar instructions of boolean materialisation
+                asm volatile("s_andn2_b64 %0, %0, %1" : "+s"(alive) : "s"(mk) : "scc");
+                if (alive == 0) break;  // every pixel of the quadrant has saturated (the outer loop ends below)
+#else
+                alive &= ~mk;
+                if (alive == 0) bm = 0;
+#endif
+            }
+        }
+        if (alive == 0) break;
+        if (GUARD) {  // chunk end: sum a/(1 - a) over the chunk's steps <= T_start / T_end - 1 (1e-5: v_rcp_f32's ULP)
+            S += __builtin_fmaf(T_cs * 1.00001f, __builtin_amdgcn_rcpf(T), -1.0f);
+            T_cs = T;
+        }
+    }
+    STAT_ADD(7, (unsigned long long)__popcll(alive) * (range.y - range.x));  // pixels that never broke walk the whole list
+    return !abandon;
+}
+
+// EXP / CONTRACT: see blend_walk.  GUARD (with a fast exp, uncontracted): break decisions inside the guard's window are resolved
+// exactly, pixel by pixel; a quadrant the fast pass abandons is re-rendered at once, by the same wave, with EXP = 2.
+template <int EXP, bool CONTRACT, bool GUARD>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blend(const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ sorted_gid,
                                                  const uint32_t* __restrict__ tile_order,
                                                  const AttrRecord* __restrict__ rec,
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
                                                  float4* __restrict__ rgba, uchar4* __restrict__ bgra,
-                                                 const Counters* __restrict__ counters, Counters* host_counters,
+                                                 Counters* __restrict__ counters, Counters* host_counters,
                                                  const FrameParams* __restrict__ fp, uint32_t* __restrict__ vis_count) {
+    static_assert(!GUARD || (EXP != 2 && !CONTRACT), "the guard belongs to a fast exp on the uncontracted arithmetic");
     if (fp) {  // graph replay: this frame's targets come from the parameter block
         rgba = reinterpret_cast<float4*>(fp->rgba);
         bgra = reinterpret_cast<uchar4*>(fp->bgra);
         host_counters = fp->host_counters;
     }
-    // wave-private slabs (no cross-wave sharing, no barriers), three planes of 64 float4 per wave: {c00 c01 c11 o} {u v r g} {b, pmin, -, -}.  Plane-major keeps the staging
-    // ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets serve the reads
+    // wave-private slabs (no cross-wave sharing, no barriers)
     __shared__ float4 s_rec[4][3][WAVE];
-    __shared__ uint2 s_exptab[EXP == 2 ? 4 : 1][32];  // wave-private copies of kExpfTab (no workgroup barrier in this kernel)
+    __shared__ uint2 s_exptab[(EXP == 2 || GUARD) ? 4 : 1][32];  // wave-private copies of kExpfTab (no workgroup barrier in this kernel)
+    __shared__ uint32_t s_klist[GUARD ? 4 : 1][GUARD ? kGuardList : 1];  // GUARD: each wave's list of kept entries (resolve_break)
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     if (EXP == 2) {
@@ -186,136 +430,32 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     const float rx0 = (float)qx0, ry0 = (float)qy0;
 
     const uint2 range = ranges[tile];
-    float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     // Pixel predicates live in 64-bit scalar masks (one bit per lane): combining them is scalar-unit work
     // and testing "any lane" is one s_cmp, where bool-typed code would spend VALU instructions on it.
-    uint64_t alive = __builtin_amdgcn_ballot_w64(inside);  // pixels still accumulating
+    const uint64_t alive = __builtin_amdgcn_ballot_w64(inside);  // pixels still accumulating
 
     if (alive != 0 && range.x < range.y) {
-        // software pipeline over 64-entry chunks: ids two chunks ahead, records one chunk ahead
-        BlendEntry nxt;
-        nxt.co = make_float4(0, 0, 0, 0);
-        nxt.uv = make_float4(0, 0, 0, 0);
-        nxt.b = 0;
-        uint32_t g_next = 0;
-        {
-            const uint32_t i0 = range.x + lane;
-            if (i0 < range.y) blend_fetch(nxt, sorted_gid[i0], rec);
-            const uint32_t i1 = i0 + WAVE;
-            if (i1 < range.y) g_next = sorted_gid[i1];
-        }
-        for (uint32_t base = range.x; base < range.y; base += WAVE) {
-            const BlendEntry cur = nxt;
-            const bool have = base + lane < range.y;
-            {   // prefetch: records of chunk +1 (ids already here), ids of chunk +2
-                const uint32_t i1 = base + WAVE + lane;
-                if (i1 < range.y) blend_fetch(nxt, g_next, rec);
-                const uint32_t i2 = i1 + WAVE;
-                if (i2 < range.y) g_next = sorted_gid[i2];
-            }
-            // classify entry `lane` of this chunk against the wave's quadrant
-            const float tau = __logf(255.0f * cur.co.w);
-            // NaN opacity: min(0.99, NaN) is 0.99 in the pipeline's definition -> the entry is never culled
-            const float lim = tau == tau ? fmaxf(tau, 0.0f) * 1.001f + 1e-3f : 3.0e38f;
-            bool keep = have && !(tau <= -1e-3f);  // tau <= 0: o*exp(p) < 1/255 for every p <= 0
-            if (keep) {
-                const float mq = min_q_rect(cur.co.x, cur.co.y, cur.co.z, cur.uv.x, cur.uv.y, rx0, rx0 + 7.0f,
-                                            ry0, ry0 + 7.0f);
-                // The rounding error of the shader's `power` (and of mq) is relative to the TERMS c00 dx^2, c11 dy^2,
-                // c01 dx dy, not to their sum: a thin diagonal splat far from its centre has terms ~1e5 cancelling to
-                // q ~ 5.  The slack therefore grows with the terms at the quadrant's corner farthest from the centre
-                // (8 roundings of 2^-24 each, generously).
-                const float ax = fmaxf(fabsf(cur.uv.x - rx0), fabsf(cur.uv.x - (rx0 + 7.0f)));
-                const float ay = fmaxf(fabsf(cur.uv.y - ry0), fabsf(cur.uv.y - (ry0 + 7.0f)));
-                const float mag = __builtin_fmaf(0.5f * fabsf(cur.co.x) * ax, ax,
-                                                 __builtin_fmaf(0.5f * fabsf(cur.co.z) * ay, ay, fabsf(cur.co.y) * ax * ay));
-                keep = !(mq > __builtin_fmaf(mag, 4.8e-7f, lim));  // NaN -> keep
-            }
-            uint64_t bm = __ballot(keep);
-            STAT_ADD(0, 1);
-            STAT_ADD(6, __popcll(__ballot(have)));
-            STAT_ADD(1, __popcll(bm));
-            if (bm == 0) continue;
-            // conic pre-scaled once per entry: (-c00/2, -c01, -c11/2).  Scaling by a power of two commutes with every
-            // rounding below, so power is bit-identical to render.comp:66 evaluated as written (with its three
-            // contractions) while the per-pixel body loses the -0.5 multiply
-            s_rec[w][0][lane] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
-            s_rec[w][1][lane] = cur.uv;
-            s_rec[w][2][lane] = make_float4(cur.b, -lim, 0.0f, 0.0f);
-
-            while (bm) {
-                const int k = __ffsll((unsigned long long)bm) - 1;
-#if GS_BLEND_SALU_DIET
-                asm("s_bitset0_b64 %0, %1" : "+s"(bm) : "s"(k));  // bm &= bm - 1 costs three scalar instructions
-#else
-                bm &= bm - 1;
-#endif
-                STAT_ADD(2, 1);                       // (entry, wave) pairs evaluated
-                STAT_ADD(3, __popcll(alive));         // lanes alive
-                float4 co = s_rec[w][0][k];
-                float4 uv = s_rec[w][1][k];
-                float4 bp = s_rec[w][2][k];
-                // all ten floats in one LDS round trip: without this the compiler sinks the loads of o, r, g, b
-                // behind the exp() branch, where 94 % of the pairs then pay a second LDS latency
-                asm volatile("" : "+v"(co.w), "+v"(uv.z), "+v"(uv.w), "+v"(bp.x));
-                const float dx = uv.x - fx;
-                const float dy = uv.y - fy;
-                // :66  -0.5 * (co.x*dx*dx + co.z*dy*dy) - co.y*dx*dy
-                float power;
-                if (CONTRACT) {
-                    const float s = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);    // FMA  (= -0.5 * the shader's sum)
-                    power = __builtin_fmaf(co.y * dx, dy, s);                         // FMA
-                } else {  // -0.5 * (c00 dx dx + c11 dy dy) - c01 dx dy, every product and sum rounded (the conic is pre-scaled)
-                    const float s = co.x * dx * dx + co.z * dy * dy;
-                    power = s + co.y * dx * dy;
+        uint32_t resolved = 0, unused;
+        bool table_ready = EXP == 2;  // GUARD: the wave copies libm's table into LDS when it first needs it
+        const bool done = blend_walk<EXP, CONTRACT, GUARD>(range, sorted_gid, rec, s_rec[w], s_exptab[(EXP == 2 || GUARD) ? w : 0],
+                                                           s_klist[GUARD ? w : 0], lane, fx, fy, rx0, ry0, alive, c0, c1, c2, resolved,
+                                                           table_ready);
+        if (GUARD && resolved != 0 && lane == 0) atomicAdd(&counters->blend_resolved, resolved);
+        if (GUARD && !done) {  // wave-uniform: the whole quadrant again, with the reference's arithmetic
+            if (!table_ready) {
+                if (lane < 32) {
+                    const uint64_t v = kExpfTab[lane];
+                    s_exptab[w][lane] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
                 }
-                // power <= 0 is false for NaN: a NaN power skips the entry (the pipeline's definition)
-                const uint64_t m1 = alive & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
-                                    __builtin_amdgcn_ballot_w64(!(power < bp.y));
-                if (m1 != 0) {
-                    STAT_ADD(4, 1);                   // pairs reaching exp
-                    STAT_ADD(5, __popcll(m1));        // lanes needing exp
-                    // :77.  EXP 1: the hardware's v_exp_f32 (what a Vulkan driver emits for exp()); 2: libm's expf, what the
-                    // reference's text compiled for the CPU calls; 0: the pipeline-defined polynomial.  The oracle reproduces
-                    // 0 and 2 bit for bit
-                    const float ex = EXP == 1   ? __builtin_amdgcn_exp2f(power * 1.44269502162933349609375f)
-                                     : EXP == 2 ? gs_expf_libm(power, s_exptab[EXP == 2 ? w : 0])
-                                                : gs_exp_blend(power);
-                    const float alpha = fminf(0.99f, co.w * ex);
-                    const uint64_t m2 = m1 & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
-                    const float test_T = T * (1 - alpha);
-                    const uint64_t mk = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);  // :82-85 break
-                    STAT_ADD(8, __popcll(m2 & ~mk));   // (pixel, entry) pairs that contribute (alpha >= 1/255, before the break)
-                    // the reference's loop walks a pixel's list up to and including the entry it breaks at (render.comp:60-85)
-                    STAT_ADD(7, (unsigned long long)__popcll(mk) * ((base - range.x) + (uint32_t)k + 1u));
-                    const bool upd = __builtin_amdgcn_inverse_ballot_w64(m2 & ~mk);
-                    if (upd) {  // the accumulate runs under the exec mask: no selects
-                        if (CONTRACT) {
-                            c0 = __builtin_fmaf(uv.z * alpha, T, c0);  // :87  FMA
-                            c1 = __builtin_fmaf(uv.w * alpha, T, c1);
-                            c2 = __builtin_fmaf(bp.x * alpha, T, c2);
-                        } else {  // c += color * alpha * T
-                            c0 = c0 + uv.z * alpha * T;
-                            c1 = c1 + uv.w * alpha * T;
-                            c2 = c2 + bp.x * alpha * T;
-                        }
-                        T = test_T;
-                    }
-#if GS_BLEND_SALU_DIET
-                    // alive &= ~mk, kept opaque: left to itself the compiler turns "did the last pixel just saturate" into
-                    // seven scalar instructions of boolean materialisation
-                    asm volatile("s_andn2_b64 %0, %0, %1" : "+s"(alive) : "s"(mk) : "scc");
-                    if (alive == 0) break;  // every pixel of the quadrant has saturated (the outer loop ends below)
-#else
-                    alive &= ~mk;
-                    if (alive == 0) bm = 0;
-#endif
-                }
+                __builtin_amdgcn_wave_barrier();
+                table_ready = true;
             }
-            if (alive == 0) break;
+            if (lane == 0) atomicAdd(&counters->blend_redo, 1u);
+            (void)blend_walk<2, false, false>(range, sorted_gid, rec, s_rec[w], s_exptab[w], nullptr, lane, fx, fy, rx0, ry0, alive, c0, c1, c2,
+                                              unused, table_ready);
         }
     }
-    STAT_ADD(7, (unsigned long long)__popcll(alive) * (range.y - range.x));  // pixels that never broke walk the whole list
     if (inside) {
         const size_t p = (size_t)py * width + px;
         if (rgba) rgba[p] = make_float4(c0, c1, c2, 1.0f);  // :98
@@ -330,25 +470,29 @@ __global__ __launch_bounds__(BLOCK) void k_blend(const uint2* __restrict__ range
     }
 }
 
-template <int EXP, bool CONTRACT>
+template <int EXP, bool CONTRACT, bool GUARD>
 static void launch_blend_as(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                             uint32_t width, uint32_t height, uint32_t tx, uint32_t ty, float* rgba, uint8_t* bgra,
-                            const Counters* counters, Counters* host_counters, const FrameParams* fp, hipStream_t s) {
-    hipLaunchKernelGGL((k_blend<EXP, CONTRACT>), dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
+                            Counters* counters, Counters* host_counters, const FrameParams* fp, hipStream_t s) {
+    hipLaunchKernelGGL((k_blend<EXP, CONTRACT, GUARD>), dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                        sorted_gid, tile_order, av.rec, width, height, tx, reinterpret_cast<float4*>(rgba),
                        reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp, av.vis_count);
 }
 
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
-                  uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
+                  uint32_t height, float* rgba, uint8_t* bgra, Counters* counters,
                   Counters* host_counters, int exp_mode, bool contract, const FrameParams* fp, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
+    if (exp_mode == 3 && !contract)  // the guarded hardware exp; with the contractions on there is nothing to guard: mode 1
+        return launch_blend_as<1, false, true>(ranges, sorted_gid, tile_order, av, width, height, tx, ty, rgba, bgra, counters,
+                                               host_counters, fp, s);
+    if (exp_mode == 3) exp_mode = 1;
 #define GS_BLEND_CASE(E, C)                                                                                              \
     if (exp_mode == E && contract == C)                                                                                  \
-        return launch_blend_as<E, C>(ranges, sorted_gid, tile_order, av, width, height, tx, ty, rgba, bgra, counters,    \
-                                     host_counters, fp, s)
+        return launch_blend_as<E, C, false>(ranges, sorted_gid, tile_order, av, width, height, tx, ty, rgba, bgra,       \
+                                            counters, host_counters, fp, s)
     GS_BLEND_CASE(0, true);
     GS_BLEND_CASE(0, false);
     GS_BLEND_CASE(1, true);
@@ -356,6 +500,69 @@ void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint
     GS_BLEND_CASE(2, true);
     GS_BLEND_CASE(2, false);
 #undef GS_BLEND_CASE
+}
+
+
+// ---- test hook: the blend's exp() implementations evaluated ON THE DEVICE over ranges of binary32 bit patterns -------------
+// (tests/test_gpu_expf.py: gs_expf_libm against the host's libm on every binary32 <= 0, and the constants of the guard)
+__global__ __launch_bounds__(BLOCK) void k_expf_scan(uint32_t first_bits, uint64_t count, unsigned long long* __restrict__ block_sums,
+                                                     unsigned long long* __restrict__ guard_max /* [2] bits of non-negative doubles */) {
+    // block b of the grid covers 2^20 consecutive patterns: one 64-bit checksum per block
+    const uint64_t base = (uint64_t)blockIdx.x << 20;
+    unsigned long long sum = 0;
+    double worst = 0.0, worst_near = 0.0;
+    for (uint32_t j = threadIdx.x; j < (1u << 20); j += BLOCK) {
+        const uint64_t at = base + j;
+        if (at >= count) break;
+        const uint32_t xb = first_bits + (uint32_t)at;
+        const float x = __uint_as_float(xb);
+        const float y = gs_expf_libm_full(x, reinterpret_cast<const uint2*>(kExpfTab));
+        sum += (unsigned long long)__float_as_uint(y) * (unsigned long long)((xb * 0x9E3779B1u) | 1u);
+        if (x >= -16.0f && x <= 0.0f) {  // the guard's premise: |v_exp_f32(fl(x log2e)) - expf(x)| <= (E0e + kGuardE1 |x|) expf(x)
+            const float fast = __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f);
+            const double rel = fabs((double)fast - (double)y) / (double)y;
+            worst = fmax(worst, rel - (double)kGuardE1 * fabs((double)x));
+            if (x >= -1.0f) worst_near = fmax(worst_near, rel);
+        }
+    }
+    // wave reduction, then one atomic per wave
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += __shfl_xor(sum, d, WAVE);
+        worst = fmax(worst, __shfl_xor(worst, d, WAVE));
+        worst_near = fmax(worst_near, __shfl_xor(worst_near, d, WAVE));
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        atomicAdd(&block_sums[blockIdx.x], sum);
+        atomicMax(&guard_max[0], (unsigned long long)__double_as_longlong(worst));       // non-negative doubles order like their bits
+        atomicMax(&guard_max[1], (unsigned long long)__double_as_longlong(worst_near));
+    }
+}
+
+extern "C" int gs_debug_expf_scan(int device, uint32_t first_bits, uint64_t count, uint64_t* block_sums, uint64_t blocks_capacity,
+                                  double* guard /* nullable [4] */) {
+    const uint64_t blocks = (count + (1u << 20) - 1) >> 20;
+    if (blocks == 0 || blocks > blocks_capacity || !block_sums || blocks > 0x7FFFFFFFull) return GS_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return GS_ERR_DEVICE;
+    unsigned long long* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), (blocks + 2) * sizeof(unsigned long long)) != hipSuccess) return GS_ERR_NOMEM;
+    int rc = GS_OK;
+    if (hipMemset(d, 0, (blocks + 2) * sizeof(unsigned long long)) != hipSuccess) rc = GS_ERR_DEVICE;
+    if (rc == GS_OK) {
+        hipLaunchKernelGGL(k_expf_scan, dim3((uint32_t)blocks), dim3(BLOCK), 0, nullptr, first_bits, count, d, d + blocks);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = GS_ERR_DEVICE;
+    }
+    unsigned long long g[2] = {0, 0};
+    if (rc == GS_OK && (hipMemcpy(block_sums, d, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(g, d + blocks, sizeof g, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = GS_ERR_DEVICE;
+    (void)hipFree(d);
+    if (rc == GS_OK && guard) {
+        guard[0] = __builtin_bit_cast(double, g[0]);  // max over x in [-16, 0] of  rel(x) - kGuardE1 |x|   (must stay below kGuardE0 - 2^-23)
+        guard[1] = __builtin_bit_cast(double, g[1]);  // max rel(x) over x in [-1, 0]
+        guard[2] = (double)kGuardE0;
+        guard[3] = (double)kGuardE1;
+    }
+    return rc;
 }
 
 #ifdef GS_BLEND_STATS

@@ -111,6 +111,8 @@ struct gs_scene {
     DevBuf<float> owned_blob;
     float* blob = nullptr;  // owned_blob.p or adopted
     DevBuf<float> cov3d;
+    bool unit_opacity = true;  // no opacity exceeds 1 (the sigmoid's range): what the guarded blend's bound assumes
+    DevBuf<float> acut;     // the alpha cut of every Gaussian: render.comp:78 as a bound on `power`, from the opacity (gs::launch_alpha_cut)
     DevBuf<uint16_t> sh16;  // gs_scene_quantize_sh: the SH block as binary16 (preprocess reads it instead)
     bool sh_half = false;
 
@@ -119,8 +121,15 @@ struct gs_scene {
         if (reinterpret_cast<uintptr_t>(blob) % 64 != 0)
             throw Error(GS_ERR_INVALID, "the scene blob must be 64-byte aligned (SH blocks are read as 16-byte vectors)");
         gs::launch_cov3d(blob, cov3d.p, static_cast<uint32_t>(n), static_cast<uint32_t>(gs::blob_stride(n)), nullptr);
+        acut.alloc(n);
+        DevBuf<uint32_t> beyond;
+        beyond.alloc(1);
+        HIP_CHECK(hipMemset(beyond.p, 0, sizeof(uint32_t)));
+        gs::launch_alpha_cut(blob, acut.p, static_cast<uint32_t>(n), static_cast<uint32_t>(gs::blob_stride(n)), beyond.p, nullptr);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(nullptr));
+        uint32_t flag = 0;
+        HIP_CHECK(hipMemcpy(&flag, beyond.p, sizeof flag, hipMemcpyDeviceToHost));  // (synchronises)
+        unit_opacity = flag == 0;
     }
 };
 
@@ -597,7 +606,11 @@ struct gs_renderer {
     static uint32_t level_limit(int lv) { return gs::kBinSortLimit[lv]; }
     int frame_level() const { return sort_mode == 1 ? kGlobalLevel : level; }
     bool graph_mode = false;     // replay each frame as one captured HIP graph (gs_set_graph_mode)
-    int exp_mode = 2;            // the blend's exp(): 2 libm's expf restated in binary64 (default), 0 pipeline polynomial, 1 hardware v_exp_f32 (gs_set_exp_mode)
+    // the blend's exp() (gs_set_exp_mode): 3 (default) the hardware's v_exp_f32 under the guard of render.comp:82 -- the reference's
+    // decisions, its pixels to rounding noise; 2 libm's expf restated in binary64 -- the reference's bits; 0 pipeline polynomial, 1 v_exp_f32
+    int exp_mode = 3;
+    // a scene that holds an opacity > 1 is outside the guard's premises: blended with mode 2's arithmetic instead
+    int blend_exp_mode() const { return exp_mode == 3 && !scene->unit_opacity ? 2 : exp_mode; }
     bool contract = false;       // the three FMA contractions GLSL permits in render.comp:66,87 (gs_set_blend_contraction); default: as written
     int min_bin_shift = 3;       // GS_BIN_SHIFT: log2 of the default bin edge in tiles (8 x 8 tiles)
     // GS_L1_DENSE_MIN: scenes of at least this many Gaussians hand level 1 the dense lists of visible Gaussians (measured
@@ -775,7 +788,7 @@ struct gs_renderer {
         ensure_tile_order(tx, ty);
 
         gs::SceneView sv{scene->blob, scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n)),
-                          scene->sh_half ? scene->sh16.p : nullptr};
+                          scene->sh_half ? scene->sh16.p : nullptr, scene->acut.p};
         gs::Counters* cnt = fb.counters.p;
         // the level-1 kernels that take their items in any order (bin-local path, bins of <= 8 x 8 tiles) stream the dense
         // list of visible Gaussians, which k_preprocess then writes beside the planes
@@ -868,7 +881,7 @@ struct gs_renderer {
                 HIP_CHECK(hipStreamWaitEvent(bstream, fb.prep_done, 0));
             }
             gs::launch_blend(fb.ranges.p, fb.sorted.p, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
-                             fused_counters ? sl.h_counters : nullptr, exp_mode, contract, fp, bstream);
+                             fused_counters ? sl.h_counters : nullptr, blend_exp_mode(), contract, fp, bstream);
         };
         depth_order = bin_local ? nullptr : fb.dvals[1].p;
         sorted_gid = fb.sorted.p;
@@ -880,7 +893,7 @@ struct gs_renderer {
             FrameBuffers::GraphKey key;
             key.level = lv;
             key.bin_shift = geo.bin_shift;
-            key.hw_exp = exp_mode;
+            key.hw_exp = blend_exp_mode();
             key.contract = contract ? 1 : 0;
             key.width = u.width;
             key.height = u.height;
@@ -1242,7 +1255,7 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
         r->scene = scene;
         r->init();
         if (const char* e = std::getenv("GS_GRAPH")) r->graph_mode = std::atoi(e) != 0;  // initial gs_set_graph_mode
-        if (const char* e = std::getenv("GS_EXP_MODE")) r->exp_mode = std::min(2, std::max(0, std::atoi(e)));  // initial gs_set_exp_mode
+        if (const char* e = std::getenv("GS_EXP_MODE")) r->exp_mode = std::min(3, std::max(0, std::atoi(e)));  // initial gs_set_exp_mode
         if (const char* e = std::getenv("GS_BLEND_CONTRACTION")) r->contract = std::atoi(e) != 0;  // initial gs_set_blend_contraction
         if (const char* e = std::getenv("GS_L1_DENSE_MIN")) r->dense_min = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("GS_BIN_SHIFT")) r->min_bin_shift = std::min(5, std::max(2, std::atoi(e)));  // default bin edge
@@ -1333,6 +1346,14 @@ int gs_get_stats(gs_renderer* r, gs_frame_stats* out) {
         out->num_gaussians = r->scene->n;
         out->instance_capacity = r->capacity;
         out->retries = r->retries;
+        // written by the blend itself, after it published the other counters: read from the device (everything has retired)
+        out->blend_redo = out->blend_resolved = 0;
+        if (r->have_frame && r->last_set && r->last_set->counters.p) {
+            gs::Counters c{};
+            HIP_CHECK(hipMemcpy(&c, r->last_set->counters.p, sizeof c, hipMemcpyDeviceToHost));
+            out->blend_redo = c.blend_redo;
+            out->blend_resolved = c.blend_resolved;
+        }
     });
 }
 
@@ -1385,8 +1406,8 @@ int gs_set_sort_path(gs_renderer* r, int mode) {
 int gs_set_exp_mode(gs_renderer* r, int mode) {
     return guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "renderer is null");
-        if (mode < 0 || mode > 2)
-            throw Error(GS_ERR_INVALID, "exp mode must be 0 (pipeline polynomial), 1 (hardware v_exp_f32) or 2 (libm's expf in binary64)");
+        if (mode < 0 || mode > 3)
+            throw Error(GS_ERR_INVALID, "exp mode must be 0 (pipeline polynomial), 1 (hardware v_exp_f32), 2 (libm's expf in binary64) or 3 (guarded v_exp_f32)");
         r->drain();
         r->exp_mode = mode;
     });
@@ -1428,9 +1449,10 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
             case GS_STAGE_CONIC_OPACITY:
             case GS_STAGE_UV_RG:
             case GS_STAGE_B:
+            case GS_STAGE_ALPHA_CUT:
                 {   // fields of the 64-byte attribute records (only the visible Gaussians' records are written: the rest
                     // of the tap is whatever an earlier frame left, like the reference's VertexAttribute buffer)
-                    const size_t width = stage == GS_STAGE_RADIUS || stage == GS_STAGE_B ? 1 : 4;
+                    const size_t width = stage == GS_STAGE_RADIUS || stage == GS_STAGE_B || stage == GS_STAGE_ALPHA_CUT ? 1 : 4;
                     if (bytes < n * width * 4) throw Error(GS_ERR_INVALID, "destination too small for stage buffer");
                     std::vector<gs::AttrRecord> recs(n);
                     if (n) HIP_CHECK(hipMemcpy(recs.data(), r->last_set->rec.p, n * sizeof(gs::AttrRecord), hipMemcpyDeviceToHost));
@@ -1439,6 +1461,7 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
                         const gs::AttrRecord& a = recs[i];
                         if (stage == GS_STAGE_RADIUS) out[i] = a.b_depth_r.z;
                         else if (stage == GS_STAGE_B) out[i] = a.b_depth_r.x;
+                        else if (stage == GS_STAGE_ALPHA_CUT) out[i] = a.b_depth_r.w;
                         else std::memcpy(out + 4 * i, stage == GS_STAGE_CONIC_OPACITY ? &a.conic_op : &a.uv_rg, 16);
                     }
                     return;

@@ -26,6 +26,7 @@ struct SceneView {
     uint32_t n;
     uint32_t stride;     // blob_stride(n)
     const uint16_t* sh16;  // nullable: the SH block as binary16, n x 48 (gs_scene_quantize_sh); read instead of the fp32 one
+    const float* acut;   // n floats: the alpha cut of every Gaussian (launch_alpha_cut), a function of its opacity, computed at load
 };
 
 // Per-frame buffers indexed by Gaussian id.
@@ -37,7 +38,7 @@ struct SceneView {
 struct AttrRecord {
     float4 conic_op;   // c00 c01 c11 opacity
     float4 uv_rg;      // u v r g
-    float4 b_depth_r;  // b, depth, radius, 0
+    float4 b_depth_r;  // b, depth, radius, alpha cut (the most negative `power` at which render.comp:78 keeps the entry)
     uint4 pad_;        // zeros (k_preprocess writes a record as one full 64-byte line); the blend never reads it
 };
 static_assert(sizeof(AttrRecord) == 64, "one line per Gaussian");
@@ -70,6 +71,9 @@ struct Counters {
     uint32_t bin_entries;  // E1: (bin, Gaussian) candidates of the level-1 binning
     uint32_t max_bin;    // candidates in the fullest bin
     uint32_t slabs;      // depth-slab descriptors written by k_bin_slabs for k_slab_work (level 4)
+    // written BY the guarded blend (the host copy, published when the blend starts, does not hold them; gs_get_stats reads the device words):
+    uint32_t blend_resolved;  // break decisions (render.comp:83) inside the guard's window, resolved by replaying the pixel exactly
+    uint32_t blend_redo;      // quadrants (8 x 8 px) abandoned and re-rendered whole with the reference's arithmetic
 };
 // What changes from one frame to the next.  Normally these travel as kernel arguments; when a frame is replayed
 // as a captured HIP graph (gs_set_graph_mode) they are read from this block in device memory instead, which the
@@ -90,6 +94,10 @@ constexpr int kBinSortMax = 16384;
 constexpr uint32_t kSlabDescBytes = 288, kSlabCapacity = 8192, kSlabWorkGroups = 512;
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s);
+// cut[i] = the most negative power <= 0 with !(min(0.99, opacity[i] * expf(power)) < 1/255)  (render.comp:77-78; +inf: none,
+// -inf: all), exact for libm's expf: the blend compares `power` with it instead of alpha with 1/255 (gs_device.h: alpha_cut)
+// *beyond_unit (device memory, nullable, zeroed by the caller): set to 1 if any opacity exceeds 1
+void launch_alpha_cut(const float* blob, float* cut, uint32_t n, uint32_t stride, uint32_t* beyond_unit, hipStream_t s);
 // fp32 SH block of the blob -> binary16 (round to nearest even), n x 48 values
 void launch_sh_to_half(const float* blob, uint16_t* sh16, uint32_t n, uint32_t stride, hipStream_t s);
 // counters (nullable): the kernel clears the frame's counters, so that a frame needs no memset node.
@@ -162,10 +170,12 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s);  // k_bin_
 // tile_order[b] = the tile workgroup b renders (a permutation of the tiles)
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
-                  uint32_t height, float* rgba, uint8_t* bgra, const Counters* counters,
+                  uint32_t height, float* rgba, uint8_t* bgra, Counters* counters,
                   Counters* host_counters /* pinned, nullable: *host_counters = *counters */,
-                  int exp_mode /* 0 pipeline polynomial, 1 v_exp_f32, 2 libm's expf restated in binary64 */,
-                  bool contract /* the pipeline's FMA contractions of render.comp:66,87 (default) or none */,
+                  int exp_mode /* 0 pipeline polynomial, 1 v_exp_f32, 2 libm's expf restated in binary64, 3 v_exp_f32 under the guard
+                                  of render.comp:82 (break decisions near the cut taken from mode 2's arithmetic; needs every
+                                  opacity <= 1: the caller passes 2 for a scene that holds a larger one) */,
+                  bool contract /* the three FMA contractions GLSL permits in render.comp:66,87, or (default) none */,
                   const FrameParams* fp, hipStream_t s);
 
 }  // namespace gs

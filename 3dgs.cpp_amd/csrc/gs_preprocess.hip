@@ -124,7 +124,7 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
 
     // what a visible lane carries from the culls to the stores
     uint32_t num_tiles = 0;
-    float px = 0, py = 0, pz = 0, depth = 0, c00 = 0, c01 = 0, c11 = 0, opacity = 0, radii = 0, uvx = 0, uvy = 0;
+    float px = 0, py = 0, pz = 0, depth = 0, c00 = 0, c01 = 0, c11 = 0, opacity = 0, acut = 0, radii = 0, uvx = 0, uvy = 0;
     int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
     if (valid) do {
         px = blob[(P_POS + 0) * N + i];
@@ -225,6 +225,7 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
         if (nt == 0) break;
         depth = p_view[2];
         opacity = blob[(size_t)P_OPACITY * N + i];
+        acut = sv.acut[i];  // render.comp:78 as a bound on `power` (computed at load from the opacity; the blend's cut)
         num_tiles = nt;
     } while (false);
     const bool vis = num_tiles != 0;
@@ -351,7 +352,7 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
     if (vis) {
         stage[0 * kPrePlane + lane] = make_float4(c00, c01, c11, opacity);
         stage[1 * kPrePlane + lane] = make_float4(uvx, uvy, rgb[0], rgb[1]);
-        stage[2 * kPrePlane + lane] = make_float4(rgb[2], depth, radii, 0.0f);
+        stage[2 * kPrePlane + lane] = make_float4(rgb[2], depth, radii, acut);
     }
     __builtin_amdgcn_wave_barrier();
     {
@@ -379,6 +380,8 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         pu.counters->bin_entries = 0;
         pu.counters->max_bin = 0;
         pu.counters->slabs = 0;
+        pu.counters->blend_resolved = 0;
+        pu.counters->blend_redo = 0;
     }
     preprocess_one(sv, u, av, i, i < sv.n, s_stage[threadIdx.x / WAVE]);
 }

@@ -1,4 +1,4 @@
-// gs_scene.hip -- load-time kernels: cov3D precompute, SH quantisation.
+// gs_scene.hip -- load-time kernels: cov3D precompute, SH quantisation, the per-Gaussian alpha cut of render.comp:78.
 //
 // Part of libgs3d_hip.so (gfx950 only).  Built with -ffp-contract=off: the floating-point contract of this path is "IEEE
 // binary32, one rounding per operation, in the order the reference shader writes it" (DESIGN.md section 3); fused
@@ -58,6 +58,21 @@ void launch_sh_to_half(const float* blob, uint16_t* sh16, uint32_t n, uint32_t s
     const uint64_t count = 48ull * n;
     hipLaunchKernelGGL(k_sh_to_half, dim3((uint32_t)((count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
                        blob + (size_t)P_SH * stride, sh16, count);
+}
+
+// The alpha cut of every Gaussian (gs_device.h: alpha_cut), a function of its opacity alone: one plane of n floats beside cov3D.
+// *beyond_unit (nullable, zeroed by the caller) is set when an opacity exceeds 1: the guarded blend's bound assumes the sigmoid's range.
+__global__ __launch_bounds__(BLOCK) void k_alpha_cut(const float* __restrict__ opacity, float* __restrict__ cut, uint32_t n,
+                                                     uint32_t* __restrict__ beyond_unit) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float o = opacity[i];
+    cut[i] = alpha_cut(o, reinterpret_cast<const uint2*>(kExpfTab));
+    if (beyond_unit && o > 1.0f) *beyond_unit = 1u;  // (racing stores of the same value)
+}
+void launch_alpha_cut(const float* blob, float* cut, uint32_t n, uint32_t stride, uint32_t* beyond_unit, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_alpha_cut, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob + (size_t)P_OPACITY * stride, cut, n, beyond_unit);
 }
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s) {

@@ -145,7 +145,7 @@ float gso_expf_libm(float x) {
     y = y * sc;
     return (float)y;
 }
-/* The same function as the HIP kernels evaluate it (gs_expf_libm in gs_kernels.hip): the cubic and the scale in FOUR
+/* The same function as the HIP kernels evaluate it (gs_expf_libm in csrc/gs_device.h): the cubic and the scale in FOUR
  * binary64 operations -- q = (C0 r + C1) r + C2;  y = q (r s) + s -- instead of glibc's five.  The binary64 values differ in
  * their last bits, their roundings to binary32 never do: gso_expf_device_mismatches counts the binary32 inputs on which
  * this sequence and this machine's libm differ, and tests/test_expf_libm.py requires 0 over every binary32 <= 0. */
@@ -168,6 +168,67 @@ float gso_expf_device(float x) {
     const double rs = r * sc;
     const double y = fma(q, rs, sc);
     return (float)y;
+}
+/* ---- render.comp:78 as a bound on `power`: the ALPHA CUT of an opacity ---------------------------------------------------
+ * kept(o, p) = !(min(0.99, o * expf(p)) < 1/255), the shader's :77-79 for one entry and one pixel.  libm's expf is monotone on
+ * p <= 0 (gso_expf_monotone_violations counts the adjacent binary32 pairs on which it is not: 0), multiplying by o > 0 and
+ * rounding are monotone, so { p <= 0 : kept } = [cut, 0]: the HIP blend decides :78 by `power >= cut` in every exp mode
+ * (csrc/gs_device.h: alpha_cut; k_alpha_cut computes the plane at load).  This is the checker's version: the same bisection
+ * over the bit patterns of the negative floats, with gso_expf_libm (pinned to libm).  +inf: nothing kept; -inf: everything. */
+static int gso_alpha_kept(float o, float p) {
+    const float alpha = fminf(0.99f, o * gso_expf_libm(p)); /* fminf(0.99, NaN) = 0.99: the pipeline's definition */
+    return !(alpha < 1.0f / 255.0f);
+}
+float gso_alpha_cut(float o) {
+    uint32_t lo = 0x80000000u, hi = 0xFF800000u; /* -0 .. -inf: a more negative value has the larger pattern */
+    float x;
+    memcpy(&x, &lo, 4);
+    if (!gso_alpha_kept(o, x)) return INFINITY;
+    memcpy(&x, &hi, 4);
+    if (gso_alpha_kept(o, x)) return -INFINITY;
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        memcpy(&x, &mid, 4);
+        if (gso_alpha_kept(o, x)) lo = mid; else hi = mid;
+    }
+    memcpy(&x, &lo, 4);
+    return x;
+}
+void gso_alpha_cut_array(const float* o, uint64_t n, float* out) {
+#pragma omp parallel for
+    for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = gso_alpha_cut(o[i]);
+}
+/* adjacent binary32 pairs (bits b, b + 1: the second is the more negative) in [first_bits, first_bits + count) on which
+ * THIS MACHINE'S expf increases as x decreases: the premise of the alpha cut.  tests/test_expf_libm.py requires 0. */
+uint64_t gso_expf_monotone_violations(uint32_t first_bits, uint64_t count) {
+    uint64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad)
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        uint32_t b0 = first_bits + (uint32_t)i, b1 = b0 + 1u;
+        float x0, x1;
+        memcpy(&x0, &b0, 4);
+        memcpy(&x1, &b1, 4);
+        if (expf(x1) > expf(x0)) ++bad;
+    }
+    return bad;
+}
+/* Checksums of THIS MACHINE'S expf over blocks of 2^20 consecutive bit patterns, the way the device hook gs_debug_expf_scan
+ * forms them of the kernels' gs_expf_libm: sums[j] = sum of bits(expf(x)) * ((bits(x) * 0x9E3779B1) | 1) mod 2^64. */
+void gso_libm_expf_block_sums(uint32_t first_bits, uint64_t count, uint64_t* sums) {
+    const int64_t blocks = (int64_t)((count + (1u << 20) - 1) >> 20);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t j = 0; j < blocks; ++j) {
+        uint64_t sum = 0;
+        for (uint64_t at = (uint64_t)j << 20; at < (((uint64_t)j + 1) << 20) && at < count; ++at) {
+            uint32_t xb = first_bits + (uint32_t)at, yb;
+            float x, y;
+            memcpy(&x, &xb, 4);
+            y = expf(x);
+            memcpy(&yb, &y, 4);
+            sum += (uint64_t)yb * (uint64_t)((xb * 0x9E3779B1u) | 1u);
+        }
+        sums[j] = sum;
+    }
 }
 /* bulk form for the exhaustive pin: out[i] = gso_expf_libm(bits -> float of first + i) */
 void gso_expf_libm_range(uint32_t first_bits, uint64_t count, float* out) {
@@ -788,6 +849,11 @@ void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const u
         for (int64_t tx = 0; tx < (int64_t)tiles_width; ++tx) {
             uint32_t start = boundaries[(tx + ty * tiles_width) * 2];
             uint32_t end = boundaries[(tx + ty * tiles_width) * 2 + 1];
+            float* cuts = NULL; /* fast exp readings: the alpha cut of the tile's entries */
+            if (!exp_libm && end > start) {
+                cuts = (float*)malloc((size_t)(end - start) * sizeof(float));
+                for (uint32_t i = start; i < end; ++i) cuts[i - start] = gso_alpha_cut(attr[payload[i]].conic_opacity[3]);
+            }
             for (uint32_t ly = 0; ly < 16; ++ly)
                 for (uint32_t lx = 0; lx < 16; ++lx) {
                     uint32_t px = (uint32_t)tx * 16 + lx, py = (uint32_t)ty * 16 + ly;
@@ -813,7 +879,10 @@ void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const u
                          * defines "no contribution". */
                         if (power > 0.0f || power != power) continue;
                         float alpha = fminf(0.99f, co[3] * (exp_libm ? gso_expf_libm(power) : gso_exp(power))); /* :77 */
-                        if (alpha < 1.0f / 255.0f) continue;
+                        /* :78.  The default reading evaluates the text.  The product's fast exp modes take this decision
+                         * from the reference's arithmetic -- power against the entry's alpha cut (gso_alpha_cut), i.e. whether
+                         * the REFERENCE's alpha is >= 1/255 -- and so does the oracle's reading of them. */
+                        if (exp_libm ? alpha < 1.0f / 255.0f : power < cuts[i - start]) continue;
                         float test_T = T * (1 - alpha);
                         if (test_T < 0.0001f) break; /* :82-85 */
                         if (contract) {
@@ -833,6 +902,7 @@ void gso_render(const gso_vertex_attr* attr, const uint32_t* boundaries, const u
                     o[2] = c2;
                     o[3] = 1.0f; /* :98 */
                 }
+            free(cuts);
         }
 }
 
@@ -902,6 +972,11 @@ void gso_render_simd(const gso_vertex_attr* attr, const uint32_t* boundaries, co
         for (int64_t tx = 0; tx < (int64_t)tiles_width; ++tx) {
             const uint32_t start = boundaries[(tx + ty * tiles_width) * 2];
             const uint32_t end = boundaries[(tx + ty * tiles_width) * 2 + 1];
+            float* cuts = NULL; /* fast exp readings: the alpha cut of the tile's entries (gso_render) */
+            if (!exp_libm && end > start) {
+                cuts = (float*)malloc((size_t)(end - start) * sizeof(float));
+                for (uint32_t i = start; i < end; ++i) cuts[i - start] = gso_alpha_cut(attr[payload[i]].conic_opacity[3]);
+            }
             for (uint32_t ly = 0; ly < 16; ++ly) {
                 const uint32_t py = (uint32_t)ty * 16 + ly;
                 if (py >= height) continue;
@@ -936,7 +1011,9 @@ void gso_render_simd(const gso_vertex_attr* attr, const uint32_t* boundaries, co
                         /* fminf(0.99f, x): the other operand when x is NaN */
                         const __m256 alpha = _mm256_min_ps(_mm256_mul_ps(_mm256_set1_ps(co[3]), exp_libm ? gso_expf_libm8(power) : gso_exp8(power)),
                                                            _mm256_set1_ps(0.99f));
-                        m = _mm256_andnot_ps(_mm256_cmp_ps(alpha, _mm256_set1_ps(1.0f / 255.0f), _CMP_LT_OQ), m);
+                        /* :78 -- the text in the default reading, power against the alpha cut in the fast exp readings (gso_render) */
+                        m = exp_libm ? _mm256_andnot_ps(_mm256_cmp_ps(alpha, _mm256_set1_ps(1.0f / 255.0f), _CMP_LT_OQ), m)
+                                     : _mm256_andnot_ps(_mm256_cmp_ps(power, _mm256_set1_ps(cuts[i - start]), _CMP_LT_OQ), m);
                         const __m256 test_T = _mm256_mul_ps(T, _mm256_sub_ps(_mm256_set1_ps(1.0f), alpha));
                         const __m256 brk = _mm256_and_ps(m, _mm256_cmp_ps(test_T, _mm256_set1_ps(0.0001f), _CMP_LT_OQ));
                         const __m256 upd = _mm256_andnot_ps(brk, m);
@@ -969,6 +1046,7 @@ void gso_render_simd(const gso_vertex_attr* attr, const uint32_t* boundaries, co
                     }
                 }
             }
+            free(cuts);
         }
 }
 

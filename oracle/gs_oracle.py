@@ -45,6 +45,9 @@ def lib():
         _LIB.gso_expf_libm.argtypes = [C.c_float]
         _LIB.gso_expf_libm_mismatches.restype = C.c_uint64
         _LIB.gso_expf_device_mismatches.restype = C.c_uint64
+        _LIB.gso_expf_monotone_violations.restype = C.c_uint64
+        _LIB.gso_alpha_cut.restype = C.c_float
+        _LIB.gso_alpha_cut.argtypes = [C.c_float]
         _LIB.gso_render_frame.restype = C.c_int
         _LIB.gso_load_ply.restype = C.c_int
         _LIB.gso_num_threads.restype = C.c_int
@@ -201,6 +204,27 @@ def expf_device_mismatches(first_bits, count):
     bad = C.c_uint32(0)
     n = lib().gso_expf_device_mismatches(C.c_uint32(first_bits), C.c_uint64(count), C.byref(bad))
     return int(n), int(bad.value)
+
+
+def expf_monotone_violations(first_bits, count):
+    """# of adjacent binary32 pairs (bits b, b + 1) in the range on which this machine's expf grows as x falls: the alpha cut's premise."""
+    return int(lib().gso_expf_monotone_violations(C.c_uint32(first_bits), C.c_uint64(count)))
+
+
+def alpha_cut(opacity):
+    """render.comp:78 as a bound on `power` (gso_alpha_cut): per opacity, the most negative power at which an entry is kept."""
+    o = np.ascontiguousarray(np.atleast_1d(opacity), np.float32)
+    out = np.empty(o.shape, np.float32)
+    lib().gso_alpha_cut_array(o.ctypes.data_as(C.c_void_p), C.c_uint64(o.size), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def libm_expf_block_sums(first_bits, count):
+    """Checksums of this machine's expf over blocks of 2^20 bit patterns, as the device hook gs_debug_expf_scan forms them."""
+    blocks = (count + (1 << 20) - 1) >> 20
+    out = np.zeros(blocks, np.uint64)
+    lib().gso_libm_expf_block_sums(C.c_uint32(first_bits), C.c_uint64(count), out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def set_simd_blend(on):

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The suite's image comparisons are assert_images_identical against the reference's shader text: that is the blend's exp
+# mode 2 (libm's expf restated), which the renderers of these tests therefore start in.  The library's default, mode 3 (the
+# guarded v_exp_f32), is selected explicitly by the tests that check it (test_gpu_guard.py, the full-size and fuzz tests).
+os.environ.setdefault("GS_EXP_MODE", "2")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402

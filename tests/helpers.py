@@ -114,6 +114,30 @@ def assert_images_identical(img, ref_img, label=""):
                              f"({bad[0][1]}, {bad[0][0]})")
 
 
+GUARD_TOL = 1e-5  # exp mode 3 against the reference text: rounding noise only (measured <= 4e-6), NO flip budget
+
+
+def assert_guarded_close(rend, u, ref_img, label=""):
+    """The frame of the library's DEFAULT blend (exp mode 3: v_exp_f32 under the guard of render.comp:82, every :78 decision
+    taken on the alpha cut) against the reference text's frame: max abs <= GUARD_TOL on every pixel -- no threshold-flip
+    budget, nothing to explain.  Returns (max abs, quadrants re-rendered with the reference's arithmetic, break decisions resolved
+    by an exact per-pixel replay); leaves the renderer in exp mode 2."""
+    rend.set_exp_mode(3)
+    rend.set_blend_contraction(False)
+    img, _ = rend.render_host(u)
+    st = rend.stats()
+    redo, resolved = st.blend_redo, st.blend_resolved
+    rend.set_exp_mode(2)
+    d = np.abs(img[..., :3].astype(np.float64) - ref_img[..., :3])
+    worst = float(d.max()) if d.size else 0.0
+    if not worst <= GUARD_TOL:
+        ys, xs = np.nonzero(d.max(axis=2) > GUARD_TOL)
+        raise AssertionError(f"{label}: guarded blend differs from the reference text by {worst:.3g} (> {GUARD_TOL}) at "
+                             f"{len(ys)} pixel(s), first (x, y) = ({xs[0]}, {ys[0]})")
+    assert (img[..., 3] == 1).all()
+    return worst, int(redo), int(resolved)
+
+
 def compare_images(img, ref_img, ref, width, label="", max_flips=None):
     """FAST-MODE comparison.  img vs ref_img (both H x W x >=3), lists taken from `ref` (attr, boundaries, sorted_payload).
     Asserts: every pixel differing by more than ULP_NOISE is an explained threshold flip (or within the cancellation bound

@@ -37,6 +37,47 @@ def test_the_kernels_operation_sequence_equals_libm_too(oracle):
     assert bad == 0, f"{bad} mismatches against libm expf, first at bits {first:#x}"
 
 
+def test_libm_expf_is_monotone_on_every_nonpositive_binary32(oracle):
+    """The premise of the ALPHA CUT (csrc/gs_device.h: alpha_cut; oracle: gso_alpha_cut): expf never grows as x falls, so
+    render.comp:78's `alpha < 1/255` is a threshold on `power` -- checked on every adjacent pair of binary32 values <= 0."""
+    lo, hi = _bits(-0.0), _bits(float("-inf"))
+    assert oracle.expf_monotone_violations(lo, hi - lo) == 0
+
+
+def test_alpha_cut_is_the_threshold_of_render_comp_78(oracle):
+    """gso_alpha_cut(o) = the most negative power kept: kept at the cut, not kept one binary32 below, for a sweep of opacities
+    (sigmoid range, the neighbourhood of 1/255, out-of-range values) -- evaluated with the literal :77-78 on libm's expf."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(0)
+    third = np.float32(1 / 255)
+    ops = np.concatenate([1 / (1 + np.exp(-rng.normal(0, 2.5, 3000))), rng.uniform(0.0039, 0.0041, 500), rng.uniform(0.9, 1.0, 300),
+                          [0.0, -1.0, third, np.nextafter(third, np.float32(0)), np.nextafter(third, np.float32(1)), 1.0, 2.0, 1e30,
+                           np.inf, np.nan, 1e-40]]).astype(np.float32)
+    cut = oracle.alpha_cut(ops)
+
+    def kept(o, p):
+        a = np.float32(o) * np.float32(libm.expf(float(p)))
+        a = np.float32(0.99) if np.isnan(a) else min(np.float32(0.99), a)
+        return not a < third
+    with np.errstate(all="ignore"):
+        for o, c in zip(ops, cut):
+            if np.isposinf(c):
+                assert not kept(o, np.float32(-0.0)), (o, c)
+            elif np.isneginf(c):
+                assert kept(o, np.float32(-np.inf)) and kept(o, np.float32(-80.0)), (o, c)
+            else:
+                assert c <= 0 and kept(o, c) and not kept(o, np.nextafter(np.float32(c), np.float32(-np.inf))), (o, c)
+                # and monotone in between: a few powers above the cut are kept, a few below are not
+                for p in (c * 0.5, c * 0.999, np.float32(-0.0)):
+                    assert kept(o, np.float32(p)), (o, c, p)
+                for p in (c * 1.001 - 1e-6, c - 1.0):
+                    assert not kept(o, np.float32(p)), (o, c, p)
+    assert cut[ops == 1.0][0] == np.float32(-5.541263)  # ln(1/255) = -5.5413: the whole sigmoid range lies above -5.55
+
+
 def test_spot_values_and_table(oracle):
     assert oracle.expf_libm(np.float32(0.0)) == 1.0 and oracle.expf_libm(np.float32(-0.0)) == 1.0
     assert oracle.expf_libm(np.float32(-1000.0)) == 0.0 and oracle.expf_libm(np.float32(-np.inf)) == 0.0

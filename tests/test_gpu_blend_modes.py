@@ -16,7 +16,7 @@ The lists and ranges never depend on the mode; switching back restores the defau
 import numpy as np
 import pytest
 
-from helpers import assert_images_identical, compare_images, compare_stages, oracle_frame
+from helpers import assert_guarded_close, assert_images_identical, compare_images, compare_stages, oracle_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,8 @@ def test_blend_modes_against_the_reference_text(pkg, oracle, gpu, case):
     assert_images_identical(img, sr["image"], label=f"{name}: default blend vs render.comp compiled for the CPU")
     assert_images_identical(img, ref["image"], label=f"{name}: default blend vs the oracle")
 
+    g_max, g_redo, g_res = assert_guarded_close(rend, u, sr["image"], label=f"{name}: guarded blend (exp mode 3)")
+    compare_stages(pkg, rend, u, sr)
     report = {}
     for exp_mode, contract in [(0, True), (0, False), (2, True), (1, True), (1, False)]:
         rend.set_exp_mode(exp_mode)
@@ -81,7 +83,8 @@ def test_blend_modes_against_the_reference_text(pkg, oracle, gpu, case):
     rend.set_blend_contraction(False)
     back, _ = rend.render_host(u)
     assert_images_identical(back, img, label=f"{name}: back to the default")
-    print(f"{name} {w}x{h} vs render.comp: default (exp 2, uncontracted) max|d| = 0 (bit-identical); "
+    print(f"{name} {w}x{h} vs render.comp: exp 2, uncontracted: max|d| = 0 (bit-identical); exp 3 (guarded, the library's default): "
+          f"max {g_max:.3g}, {g_res} decisions resolved exactly, {g_redo} quadrants re-rendered; "
           + "; ".join(f"exp {e}{' contracted' if c else ''}: max {m:.3g}, {n4} px > 1e-4, {n5} px > 1e-5"
                       for (e, c), (m, n4, n5) in report.items()))
     if name == "needles":

@@ -8,7 +8,7 @@ instance multiset equals sum(tiles_overlap), re-rendering is deterministic.
 import numpy as np
 import pytest
 
-from helpers import assert_images_identical, compare_images
+from helpers import assert_guarded_close, assert_images_identical, compare_images
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,9 @@ def against_the_reference_text(label, rend, u, img, ref, w, h, max_flips=None):
     assert gsref is not None, "oracle/_ref did not travel to this box: the parity gate against the reference text cannot run"
     rimg = gsref.render(ref["attr"], ref["boundaries"], ref["sorted_payload"], w, h)
     assert_images_identical(img, rimg, label=f"{label}: default blend vs render.comp")
+    # the library's default blend (exp mode 3, guarded): rounding noise everywhere, no flip budget
+    g_max, g_redo, g_res = assert_guarded_close(rend, u, rimg, label=f"{label}: guarded blend vs render.comp")
+    print(f"{label}: guarded blend (exp mode 3) max|d| {g_max:.3g} vs render.comp, {g_res} break decisions resolved by exact replay, {g_redo} of {((w + 7) // 8) * ((h + 7) // 8)} quadrants re-rendered")
     rend.set_fast_blend(True)
     fast, _ = rend.render_host(u)
     rend.set_fast_blend(False)

@@ -48,6 +48,8 @@ def test_random_case(pkg, oracle, gpu, seed):
     if gsref.available() and n <= 60000:  # the scalar reference text is the slow side
         rimg = gsref.render(ref["attr"], ref["boundaries"], ref["sorted_payload"], w, h)
         np.testing.assert_array_equal(img.view(np.uint32), rimg.view(np.uint32))
+    from helpers import assert_guarded_close
+    assert_guarded_close(rend, u, ref["image"], label=f"fuzz {seed}: guarded blend")  # the library's default mode: no flips, ever
     rend.set_fast_blend(True)
     fast, _ = rend.render_host(u)
     with oracle.fast_reading():

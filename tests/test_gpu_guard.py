@@ -1,0 +1,201 @@
+"""The library's default blend -- exp mode 3: the hardware's v_exp_f32 with the reference's decisions -- against the reference's
+shader text, and the two mechanisms that make its decisions the reference's:
+
+  * render.comp:78 (`alpha < 1/255 -> continue`) is decided on `power` against the Gaussian's ALPHA CUT, computed at load from the
+    opacity with libm's expf (GS_STAGE_ALPHA_CUT): the tap must equal the checker's bisection (oracle.alpha_cut) and satisfy its
+    defining property against THIS MACHINE's libm, edge opacities included;
+  * render.comp:82 (`T (1 - alpha) < 1e-4 -> break`) is guarded: quadrants in which a pixel comes within the proven window of the
+    threshold are re-rendered with exp mode 2's arithmetic.
+
+The adversarial scene puts thousands of pixels on both cuts at once: a stack of screen-filling splats whose accumulated
+transmittance crosses 1e-4 along dozens of rings (adjacent pixels a few 1e-4 apart in T), weak layers whose alpha crosses 1/255
+along others, loud colours behind the break so that a single wrong decision moves a pixel by 1e-4 .. 1e-3.  The guarded blend
+must stay within 1e-5 of the reference text there; the unguarded v_exp_f32 (mode 1) is shown not to.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import GUARD_TOL, assert_guarded_close, assert_images_identical, compare_stages
+
+pytestmark = pytest.mark.gpu
+SH_C0 = 0.28209479177387814
+
+
+def _vertices(pos, scale, opacity, rgb):
+    """GSScene::Vertex records (60 floats): position(4) scale(3) opacity rotation(4) sh(48); view-independent colour rgb."""
+    n = len(pos)
+    v = np.zeros((n, 60), np.float32)
+    v[:, 0:3] = pos
+    v[:, 3] = 1.0
+    v[:, 4:7] = np.asarray(scale, np.float32).reshape(n, -1)
+    v[:, 7] = opacity
+    v[:, 8] = 1.0
+    v[:, 12:15] = (np.asarray(rgb, np.float64) - 0.5) / SH_C0  # SH degree 0: colour = SH_C0 * dc + 0.5
+    return v
+
+
+def adversarial_vertices(shift=(0.0, 0.0), strong=0.9003, weak_layers=60, seed=0):
+    """One stack of screen-filling isotropic splats (sigma ~ 2500 px at 512 x 512).  Four strong layers: (1 - 0.9003 e^p)^4
+    crosses 1e-4 on a ring of ~65 px radius; behind them `weak_layers` layers of opacity 0.00393 .. 0.0046 (alpha crosses 1/255 on
+    rings of their own, and each kept layer moves T by 0.4 %: one more T-ring per layer) in colours of magnitude ~100."""
+    rng = np.random.default_rng(seed)
+    n = 4 + weak_layers
+    z = -(5.0 + 0.01 * np.arange(n))
+    pos = np.stack([np.full(n, shift[0]), np.full(n, shift[1]), z], axis=1)
+    opacity = np.concatenate([np.full(4, strong), rng.uniform(0.00393, 0.0046, weak_layers)]).astype(np.float32)
+    rgb = np.concatenate([rng.uniform(0.2, 1.0, (4, 3)), rng.uniform(-100.0, 100.0, (weak_layers, 3))])
+    rgb[4:, 0] = np.abs(rgb[4:, 0])  # (the red channel is clamped at 0 by preprocess.comp)
+    return _vertices(pos, np.full((n, 3), 20.0), opacity, rgb)
+
+
+def _reference(oracle, verts, w, h):
+    import __graft_entry__ as entry
+    gsref = entry.load_ref()
+    u = oracle.camera_uniforms(oracle.default_camera(), w, h)
+    ref = oracle.stages(np.ascontiguousarray(verts).view(oracle.VERTEX_DT).reshape(-1), u)
+    if gsref.available():
+        rimg = gsref.render(ref["attr"], ref["boundaries"], ref["sorted_payload"], w, h)
+        assert_images_identical(ref["image"], rimg, label="oracle vs render.comp on the adversarial scene")
+    return u, ref
+
+
+def _adversarial_case(pkg, oracle, case):
+    w = h = 512
+    rng = np.random.default_rng(100 + case)
+    verts = adversarial_vertices(shift=tuple(rng.uniform(-0.3, 0.3, 2)), strong=float(rng.uniform(0.9001, 0.9012)), seed=case)
+    u_ref, ref = _reference(oracle, verts, w, h)
+    scene = pkg.Scene.from_vertices(verts, device=0)
+    rend = pkg.Renderer(scene)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    assert u.tobytes() == u_ref.tobytes()
+    rend.set_exp_mode(2)
+    exact, _ = rend.render_host(u)
+    compare_stages(pkg, rend, u, ref)
+    assert_images_identical(exact, ref["image"], label="exp mode 2 on the adversarial scene")
+    # how adversarial: pixels whose break decision sits within 1e-6 / 1e-4 (relative) of the threshold, from a float64 trace
+    near6, near4 = _pixels_near_the_t_cut(ref, w, h)
+    assert near4 > 500, near4
+    worst, redo, resolved = assert_guarded_close(rend, u, ref["image"], label=f"adversarial {case}: guarded blend")
+    assert resolved + redo > 0  # the guard did act (what it resolved exactly is what keeps the frame within rounding noise)
+    rend.set_exp_mode(1)  # the same exp WITHOUT the guard: the decisions it protects do flip here
+    loose, _ = rend.render_host(u)
+    d1 = np.abs(loose[..., :3].astype(np.float64) - ref["image"][..., :3]).max(axis=2)
+    print(f"adversarial {case}: {near4} px within 1e-4 of the T cut, {near6} within 1e-6; guarded max|d| {worst:.3g}, {resolved} break decisions resolved exactly, "
+          f"{redo} of {(w // 8) * (h // 8)} quadrants re-rendered; unguarded v_exp_f32: max|d| {d1.max():.3g}, {int((d1 > GUARD_TOL).sum())} px > 1e-5")
+    rend.close()
+    scene.close()
+    return int((d1 > GUARD_TOL).sum())
+
+
+def test_adversarial_scenes_on_both_cuts(pkg, oracle, gpu):
+    """Six stacks (centre, strong opacity and weak layers vary): the guarded blend within 1e-5 of the reference text on each, and
+    over the six the UNGUARDED hardware exp must get at least one break wrong (otherwise the scenes prove nothing)."""
+    total = sum(_adversarial_case(pkg, oracle, case) for case in range(6))
+    assert total >= 1, "no unguarded flip on any adversarial case: the scenes do not sit on the cut"
+
+
+def _pixels_near_the_t_cut(ref, w, h):
+    """float64 re-trace of the (single-stack) adversarial scene: per pixel the smallest |T (1 - alpha) / 1e-4 - 1| met."""
+    attr = ref["attr"]
+    order = ref["sorted_payload"][ref["boundaries"][0]:ref["boundaries"][1]]  # every tile holds the whole stack, in depth order
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    T = np.ones((h, w))
+    alive = np.ones((h, w), bool)
+    near = np.full((h, w), np.inf)
+    for g in order:
+        co = attr["conic_opacity"][g].astype(np.float64)
+        dx, dy = attr["uv"][g][0] - xs, attr["uv"][g][1] - ys
+        power = -0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy
+        alpha = np.minimum(0.99, co[3] * np.exp(np.minimum(power, 0)))
+        kept = alive & (power <= 0) & (alpha >= 1.0 / 255.0)
+        test_T = T * (1 - alpha)
+        near = np.where(kept, np.minimum(near, np.abs(test_T / 1e-4 - 1)), near)
+        brk = kept & (test_T < 1e-4)
+        T = np.where(kept & ~brk, test_T, T)
+        alive &= ~brk
+    return int((near < 1e-6).sum()), int((near < 1e-4).sum())
+
+
+def test_alpha_cut_tap_equals_the_checkers_and_libm(pkg, oracle, gpu):
+    """GS_STAGE_ALPHA_CUT of every visible Gaussian == oracle.alpha_cut(opacity) (bisection over gso_expf_libm), and the cut's
+    defining property holds against THIS MACHINE's libm: kept at the cut, not kept one binary32 below it."""
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    rec = pkg.synth.synth_records(20000, seed=3, kind="A")
+    verts = oracle.activate_records(rec)
+    opacity = verts["scale_opacity"][:, 3]  # (a view: GSScene::Vertex keeps the opacity in scale_opacity.w)
+    # edge opacities on the first Gaussians: 0, negative, exactly 1/255 and its neighbours, 1, > 1, huge, inf, NaN, denormal
+    edge = np.array([0.0, -0.5, 1 / 255, np.nextafter(np.float32(1 / 255), np.float32(0)), np.nextafter(np.float32(1 / 255), np.float32(1)),
+                     1.0, 0.99, 0.9899999, 1.5, 1e30, np.inf, np.nan, 1e-40, 0.0039, 0.00393], np.float32)
+    opacity[:len(edge)] = edge
+    w = h = 256
+    scene = pkg.Scene.from_vertices(verts, device=0)
+    rend = pkg.Renderer(scene)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    rend.render_host(u)
+    vis = rend.stage("tiles") != 0
+    cut = rend.stage("alpha_cut")
+    want = oracle.alpha_cut(opacity)
+    np.testing.assert_array_equal(cut[vis].view(np.uint32), want[vis].view(np.uint32))
+    assert vis[:len(edge)].sum() >= 8  # most of the edge cases are on screen
+
+    def kept(o, p):
+        a = np.float32(o) * np.float32(libm.expf(float(p)))
+        a = np.float32(0.99) if np.isnan(a) else min(np.float32(0.99), a)
+        return not a < np.float32(1.0 / 255.0)
+    for i in np.nonzero(vis)[0][:3000]:
+        o, c = opacity[i], cut[i]
+        if np.isposinf(c):
+            assert not kept(o, np.float32(-0.0)), (o, c)
+        elif np.isneginf(c):
+            assert kept(o, np.float32(-np.inf)) and kept(o, np.float32(-50.0)), (o, c)
+        else:
+            below = np.nextafter(np.float32(c), np.float32(-np.inf))
+            assert c <= 0 and kept(o, c) and not kept(o, below), (o, c)
+    # and the frame with those opacities: mode 2 bit-identical to the checker's reference reading, mode 3 within rounding noise
+    ref = oracle.stages(verts, oracle.camera_uniforms(oracle.default_camera(), w, h))
+    rend.set_exp_mode(2)
+    img, _ = rend.render_host(u)
+    finite = np.isfinite(ref["image"]).all(axis=2)
+    np.testing.assert_array_equal(np.isfinite(img).all(axis=2), finite)
+    assert_images_identical(np.where(finite[..., None], img, 0), np.where(finite[..., None], ref["image"], 0), label="edge opacities, exp mode 2")
+    rend.set_exp_mode(3)
+    g, _ = rend.render_host(u)
+    d = np.abs(np.where(finite[..., None], g, 0).astype(np.float64) - np.where(finite[..., None], ref["image"], 0))
+    assert d.max() <= GUARD_TOL, d.max()
+    rend.close()
+    scene.close()
+
+
+def test_guard_state_survives_mode_switches_and_frames_in_flight(pkg, oracle, gpu):
+    """Mode 3 with three frames in flight and HIP-graph replay renders the same frame as one frame at a time; switching
+    3 -> 2 -> 3 changes nothing; with the contractions on, mode 3 runs as mode 1 (documented)."""
+    rec = pkg.synth.synth_records(30000, seed=11, kind="A")
+    w, h = 400, 300
+    scene = pkg.Scene.from_records(rec, device=0)
+    rend = pkg.Renderer(scene)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    rend.set_exp_mode(3)
+    a, _ = rend.render_host(u)
+    redo, resolved = rend.stats().blend_redo, rend.stats().blend_resolved
+    rend.set_exp_mode(2)
+    rend.render_host(u)
+    assert rend.stats().blend_redo == 0 and rend.stats().blend_resolved == 0  # the exact mode has nothing to guard
+    rend.set_exp_mode(3)
+    rend.set_frames_in_flight(3)
+    rend.set_graph_mode(True)
+    for _ in range(7):
+        b, _ = rend.render_host(u)
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert rend.stats().blend_redo == redo and rend.stats().blend_resolved == resolved
+    rend.set_graph_mode(False)
+    rend.set_blend_contraction(True)
+    c3, _ = rend.render_host(u)
+    rend.set_exp_mode(1)
+    c1, _ = rend.render_host(u)
+    np.testing.assert_array_equal(c3.view(np.uint32), c1.view(np.uint32))
+    rend.close()
+    scene.close()
