@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_struct_layouts(pkg):
     assert pkg.binding.UNIFORMS_DT.itemsize == 160  # std140 block, Renderer.h:21-29
     assert pkg.binding.CAMERA_DT.itemsize == 40
-    assert ctypes.sizeof(pkg.binding.FrameStats) == 88
+    assert ctypes.sizeof(pkg.binding.FrameStats) == 96  # gs_frame_stats: + blend_resolved and a pad word (round 4)
 
 
 def test_camera_uniforms_match_oracle_bitwise(pkg, oracle):
