@@ -60,7 +60,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_set_blend_contraction", "gs_get_timing_totals",
            "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_debug_expf_scan", "gs_renderer_stream",
            "gs_dist_unique_id", "gs_dist_create", "gs_dist_rank", "gs_dist_world", "gs_dist_pose_count",
-           "gs_dist_broadcast_scene", "gs_dist_broadcast_scene_ex", "gs_dist_destroy"]
+           "gs_dist_broadcast_scene", "gs_dist_broadcast_scene_ex", "gs_dist_verify", "gs_dist_destroy"]
 
 
 class FrameStats(C.Structure):

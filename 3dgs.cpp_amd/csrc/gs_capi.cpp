@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -516,16 +517,19 @@ struct FrameBuffers {
         depth.alloc(n);
         aabb.alloc(n);
         rec.alloc(n);
-        vis_region_slots = gs::vis_region_slots(static_cast<uint32_t>(n));
-        vis.alloc(static_cast<size_t>(gs::kVisRegions) * vis_region_slots);
-        vis_count.alloc(gs::kVisRegions * gs::kVisCounterStride);
-        HIP_CHECK(hipMemset(vis_count.p, 0, vis_count.n * sizeof(uint32_t)));  // every frame's LAST kernel zeroes them again
+        vis_region_slots = gs::vis_region_slots(static_cast<uint32_t>(n));  // (the lists themselves: ensure_dense_lists, on first use)
         l1_hist.alloc(1025 * static_cast<size_t>(gs::bin_level1_columns(static_cast<uint32_t>(n))));  // + the row of visible counts
         bin_count.alloc(1024);
         counters.alloc(1);
         params.alloc(1);
         set_capacity(capacity);
         ready = true;
+    }
+    void ensure_dense_lists() {  // the dense lists of visible Gaussians: only scenes of >= dense_min Gaussians ever use them (16 B x N)
+        if (vis.p) return;
+        vis.alloc(static_cast<size_t>(gs::kVisRegions) * vis_region_slots);
+        vis_count.alloc(gs::kVisRegions * gs::kVisCounterStride);
+        HIP_CHECK(hipMemset(vis_count.p, 0, vis_count.n * sizeof(uint32_t)));  // every frame's LAST kernel zeroes them again
     }
     void ensure_depth_order() {  // the global depth-order path's buffers
         if (dkeys[0].p) return;
@@ -602,6 +606,12 @@ struct gs_renderer {
     int sort_mode = 0;           // 0 auto, 1 global depth order, 2 bin-local (forced: a bin beyond 16384 is an error)
     int level = 0;
     uint32_t frames_since_fallback = 0;
+    // Depth slabs (level 4) can fail for reasons that have nothing to do with the bin's size -- one depth bucket beyond a slab, a
+    // run of more than 64 exactly equal depths inside one, more slabs than descriptors: the frame then goes to the global path,
+    // and since `max_bin` still fits level 4 the step-down below would send it straight back into the same failure every 32
+    // frames, for ever (round-3 advisor finding).  Each such failure doubles the frames the renderer stays on the global path
+    // before it tries the slabs again (32 .. 8192); 64 clean frames at level 4 reset it.
+    uint32_t slab_hold = 32, slab_clean_frames = 0;
     static constexpr int kGlobalLevel = gs::kBinSortLevels;
     static uint32_t level_limit(int lv) { return gs::kBinSortLimit[lv]; }
     int frame_level() const { return sort_mode == 1 ? kGlobalLevel : level; }
@@ -794,6 +804,10 @@ struct gs_renderer {
         // list of visible Gaussians, which k_preprocess then writes beside the planes
         const bool l1_any_order = bin_local && geo.bin_shift <= 3;
         const bool dense_list = GS_L1_DENSE && l1_any_order && n != 0 && n >= dense_min && u.width != 0 && u.height != 0;  // (the blend zeroes the lists' counters)
+        if (dense_list && !fb.vis.p) {
+            drain();
+            fb.ensure_dense_lists();
+        }
         gs::AttrView av{fb.tiles.p, fb.depth.p, fb.aabb.p, fb.rec.p, dense_list ? fb.vis.p : nullptr, dense_list ? fb.vis_count.p : nullptr,
                         fb.vis_region_slots};
 
@@ -979,6 +993,11 @@ struct gs_renderer {
             pending = 0;
             prev_retired = false;
             if (bin_too_big) {  // a bin outgrew the in-LDS order of this level: one level up from here on
+                const bool slabs_unsuitable = failed_level == gs::kBinSlabLevel && fullest <= level_limit(gs::kBinSlabLevel);
+                if (slabs_unsuitable) {  // not the bin's size: equal or crowded depths (see slab_hold)
+                    slab_hold = std::min<uint32_t>(slab_hold * 2, 8192);
+                    slab_clean_frames = 0;
+                }
                 int wanted = failed_level + 1;
                 while (wanted < kGlobalLevel && fullest > level_limit(wanted)) ++wanted;
                 if (wanted >= gs::kBinSlabLevel && can_refine(sl.u)) {  // smaller bins before slabs or the global path
@@ -986,7 +1005,9 @@ struct gs_renderer {
                     wanted = gs::kBinSlabLevel - 1;
                 } else {
                     if (sort_mode == 2 && wanted >= kGlobalLevel)
-                        throw Error(GS_ERR_OVERFLOW, "a bin holds more candidates than the bin-local sort can order");
+                        throw Error(GS_ERR_OVERFLOW, slabs_unsuitable
+                                        ? "a bin's depths are too crowded for the bin-local order (one depth bucket beyond a slab, or more than 64 equal depths in one): needs the global depth-order path"
+                                        : "a bin holds more candidates than the bin-local sort can order");
                     level = std::max(level, wanted);
                 }
                 if (refined) level = std::max(level, wanted);
@@ -1005,9 +1026,11 @@ struct gs_renderer {
             return;
         }
         redo_chain = 0;
+        if (sl.level == gs::kBinSlabLevel && ++slab_clean_frames >= 64) slab_hold = 32;  // the slabs work on this scene (again)
         if (sort_mode != 1 && level > 0) {  // one level down once the bins have fitted it for a while
             if (sl.h_counters->max_bin <= level_limit(level - 1) * 7 / 8) {
-                if (++frames_since_fallback >= 32) {
+                // (from the global path back to the slabs: only after slab_hold frames, see there)
+                if (++frames_since_fallback >= (level == kGlobalLevel ? slab_hold : 32u)) {
                     --level;
                     frames_since_fallback = 0;
                 }
@@ -1015,7 +1038,7 @@ struct gs_renderer {
                 frames_since_fallback = 0;
             }
         } else if (sort_mode != 1 && refined) {  // at the smallest order with the small bins: try the default bins again
-            if (sl.h_counters->max_bin <= level_limit(0) / 2) {  // four times the tiles per bin should still fit level 2
+            if (sl.h_counters->max_bin <= level_limit(0) / 2) {  // four times the tiles per bin should still fit level 3 (<= 16384)
                 if (++frames_since_fallback >= 32) {
                     refined = false;
                     level = gs::kBinSlabLevel - 1;
@@ -1529,6 +1552,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl& rccl() {
@@ -1543,10 +1568,12 @@ Rccl& rccl() {
         x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(::dlsym(x.lib, "ncclCommInitRank"));
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(::dlsym(x.lib, "ncclCommDestroy"));
         x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(::dlsym(x.lib, "ncclBroadcast"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(::dlsym(x.lib, "ncclAllReduce"));
+        x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(::dlsym(x.lib, "ncclGetVersion"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(::dlsym(x.lib, "ncclGetErrorString"));
         return x;
     }();
-    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString)
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.AllReduce || !r.GetVersion || !r.GetErrorString)
         throw Error(GS_ERR_DEVICE, "librccl.so could not be loaded (multi-GPU entry points need RCCL)");
     return r;
 }
@@ -1559,6 +1586,8 @@ struct gs_dist {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
+    double broadcast_ms = 0.0;   // wall time of the last scene broadcast on this rank (header + blob, to completion)
+    uint64_t broadcast_bytes = 0;
     ~gs_dist() {
         if (comm) (void)rccl().CommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1609,6 +1638,11 @@ int gs_dist_broadcast_scene_ex(gs_dist* d, gs_scene* mine, int root, unsigned fl
         if (root < 0 || root >= d->world) throw Error(GS_ERR_INVALID, "root out of range");
         if (d->rank == root && !mine) throw Error(GS_ERR_INVALID, "the root rank must pass its scene");
         HIP_CHECK(hipSetDevice(d->device));
+        const auto t_start = std::chrono::steady_clock::now();
+        auto stamp = [&](uint64_t floats) {
+            d->broadcast_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+            d->broadcast_bytes = floats * sizeof(float);
+        };
         // (1) a two-word header: the Gaussian count and the scene's storage flags (bit 0: SH kept as binary16 -- every replica
         // must render from the same coefficients as the root), (2) the packed blob: 11 padded SoA planes + the SH block, one message
         DevBuf<uint64_t> d_hdr;
@@ -1628,6 +1662,7 @@ int gs_dist_broadcast_scene_ex(gs_dist* d, gs_scene* mine, int root, unsigned fl
             nccl_check(rccl().Broadcast(mine->blob, mine->blob, gs::blob_floats(n), ncclFloat32, root, d->comm, d->stream),
                        "ncclBroadcast(scene)");
             HIP_CHECK(hipStreamSynchronize(d->stream));
+            stamp(gs::blob_floats(n));
             *out = mine;
             return;
         }
@@ -1640,6 +1675,7 @@ int gs_dist_broadcast_scene_ex(gs_dist* d, gs_scene* mine, int root, unsigned fl
         nccl_check(rccl().Broadcast(send, s->blob, gs::blob_floats(n), ncclFloat32, root, d->comm, d->stream),
                    "ncclBroadcast(scene)");
         HIP_CHECK(hipStreamSynchronize(d->stream));
+        stamp(gs::blob_floats(n));
         s->finish_load();  // cov3D is recomputed locally: 24 B / Gaussian of arithmetic instead of 24 B over xGMI
         if (hdr[1] & 1ull) quantize_sh(s.get());  // 96 B / Gaussian of local rounding instead of 96 B over xGMI
         *out = s.release();
@@ -1648,6 +1684,37 @@ int gs_dist_broadcast_scene_ex(gs_dist* d, gs_scene* mine, int root, unsigned fl
 
 int gs_dist_broadcast_scene(gs_dist* d, gs_scene* mine, int root, gs_scene** out) {
     return gs_dist_broadcast_scene_ex(d, mine, root, 0u, out);
+}
+
+int gs_dist_verify(gs_dist* d, const gs_scene* scene, gs_dist_report* out) {
+    return guarded([&] {
+        if (!d || !scene || !out) throw Error(GS_ERR_INVALID, "null argument");
+        HIP_CHECK(hipSetDevice(d->device));
+        // three words through the collective: a one from every rank (sum), this rank's checksum of its replica (min, max)
+        DevBuf<uint64_t> w;
+        w.alloc(4);
+        gs::launch_blob_checksum(scene->blob, gs::blob_floats(scene->n), w.p + 3, d->stream);
+        HIP_CHECK(hipGetLastError());
+        uint64_t h[4] = {1, 0, 0, 0};
+        HIP_CHECK(hipMemcpyAsync(w.p, h, sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
+        HIP_CHECK(hipMemcpyAsync(w.p + 1, w.p + 3, sizeof(uint64_t), hipMemcpyDeviceToDevice, d->stream));
+        HIP_CHECK(hipMemcpyAsync(w.p + 2, w.p + 3, sizeof(uint64_t), hipMemcpyDeviceToDevice, d->stream));
+        nccl_check(rccl().AllReduce(w.p, w.p, 1, ncclUint64, ncclSum, d->comm, d->stream), "ncclAllReduce(ranks)");
+        nccl_check(rccl().AllReduce(w.p + 1, w.p + 1, 1, ncclUint64, ncclMin, d->comm, d->stream), "ncclAllReduce(checksum min)");
+        nccl_check(rccl().AllReduce(w.p + 2, w.p + 2, 1, ncclUint64, ncclMax, d->comm, d->stream), "ncclAllReduce(checksum max)");
+        HIP_CHECK(hipMemcpyAsync(h, w.p, sizeof h, hipMemcpyDeviceToHost, d->stream));
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        int version = 0;
+        nccl_check(rccl().GetVersion(&version), "ncclGetVersion");
+        *out = gs_dist_report{};
+        out->ranks = h[0];
+        out->world = static_cast<uint64_t>(d->world);
+        out->checksum = h[3];
+        out->checksums_equal = h[1] == h[2] && h[1] == h[3] ? 1u : 0u;
+        out->rccl_version = static_cast<uint32_t>(version);
+        out->broadcast_ms = d->broadcast_ms;
+        out->broadcast_bytes = d->broadcast_bytes;
+    });
 }
 
 void gs_dist_destroy(gs_dist* d) { delete d; }

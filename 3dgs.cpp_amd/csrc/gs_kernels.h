@@ -98,6 +98,8 @@ void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, 
 // -inf: all), exact for libm's expf: the blend compares `power` with it instead of alpha with 1/255 (gs_device.h: alpha_cut)
 // *beyond_unit (device memory, nullable, zeroed by the caller): set to 1 if any opacity exceeds 1
 void launch_alpha_cut(const float* blob, float* cut, uint32_t n, uint32_t stride, uint32_t* beyond_unit, hipStream_t s);
+// *out (device) = sum of the blob's 32-bit patterns, as 64-bit integers (wrapping): what gs_dist_verify compares across ranks
+void launch_blob_checksum(const float* blob, uint64_t floats, uint64_t* out, hipStream_t s);
 // fp32 SH block of the blob -> binary16 (round to nearest even), n x 48 values
 void launch_sh_to_half(const float* blob, uint16_t* sh16, uint32_t n, uint32_t stride, hipStream_t s);
 // counters (nullable): the kernel clears the frame's counters, so that a frame needs no memset node.

@@ -75,6 +75,20 @@ void launch_alpha_cut(const float* blob, float* cut, uint32_t n, uint32_t stride
     hipLaunchKernelGGL(k_alpha_cut, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob + (size_t)P_OPACITY * stride, cut, n, beyond_unit);
 }
 
+// Checksum of a scene replica (gs_dist_verify): the sum of the blob's bit patterns.
+__global__ __launch_bounds__(BLOCK) void k_blob_checksum(const uint32_t* __restrict__ words, uint64_t count, unsigned long long* __restrict__ out) {
+    unsigned long long sum = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (uint64_t)gridDim.x * BLOCK) sum += words[i];
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && sum != 0) atomicAdd(out, sum);
+}
+void launch_blob_checksum(const float* blob, uint64_t floats, uint64_t* out, hipStream_t s) {
+    (void)hipMemsetAsync(out, 0, sizeof(uint64_t), s);
+    if (floats == 0) return;
+    hipLaunchKernelGGL(k_blob_checksum, dim3(2048), dim3(BLOCK), 0, s, reinterpret_cast<const uint32_t*>(blob), floats,
+                       reinterpret_cast<unsigned long long*>(out));
+}
+
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_cov3d, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob, cov3d, n, stride);

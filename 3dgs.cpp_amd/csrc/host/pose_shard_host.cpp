@@ -65,6 +65,19 @@ int main(int argc, char** argv) {
     if (rank == 0) check(gs_scene_load_ply(ply.c_str(), device, &loaded), "gs_scene_load_ply");
     gs_scene* scene = nullptr;
     check(gs_dist_broadcast_scene(dist, loaded, 0, &scene), "gs_dist_broadcast_scene");
+    // what the collective saw: every rank took part, every rank holds the root's scene (one JSON line per rank)
+    gs_dist_report rep{};
+    check(gs_dist_verify(dist, scene, &rep), "gs_dist_verify");
+    std::printf("{\"rccl\": {\"rank\": %d, \"ranks\": %llu, \"world_size\": %llu, \"version\": %u, \"blob_MB\": %.1f, \"broadcast_ms\": %.3f, "
+                "\"blob_checksums_equal\": %s, \"blob_checksum\": %llu}}\n",
+                rank, static_cast<unsigned long long>(rep.ranks), static_cast<unsigned long long>(rep.world), rep.rccl_version,
+                rep.broadcast_bytes / 1e6, rep.broadcast_ms, rep.checksums_equal ? "true" : "false",
+                static_cast<unsigned long long>(rep.checksum));
+    if (rep.ranks != static_cast<uint64_t>(world) || !rep.checksums_equal) {
+        std::fprintf(stderr, "error: the collective saw %llu of %d ranks, replicas %s\n", static_cast<unsigned long long>(rep.ranks), world,
+                     rep.checksums_equal ? "equal" : "DIFFER");
+        return 1;
+    }
 
     gs_renderer* rend = nullptr;
     check(gs_renderer_create(scene, &rend), "gs_renderer_create");

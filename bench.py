@@ -6,12 +6,16 @@
 
 A "step" is one frame: preprocess -> level-1 binning (count, scan, scatter) -> per-bin depth order + tile
 lists -> blend, over the synthetic scene S(1e6) at 1920x1080 (BASELINE configs[1]); the scene is resident in
-HBM before the timed region and the RGBA32F frame stays in HBM.  The blend runs in its DEFAULT mode -- bit-identical
-to the reference's render.comp compiled for the CPU (libm's expf restated in binary64, no contraction); the opt-in
-fast modes are timed beside it as diagnostics (`frames_per_s_fast_blend`, `frames_per_s_hw_exp`) and the measured
-distance of both from the reference text on the benched frame is in `parity`.  With N > 1 the scene blob is
-broadcast once over RCCL/xGMI and every rank renders its own camera pose (configs[3]): no per-frame
-collective, weak scaling, value = N*K frames / max-over-ranks time.
+HBM before the timed region and the RGBA32F frame stays in HBM.  The blend runs in the library's DEFAULT mode -- exp mode 3:
+the hardware's v_exp_f32 with the reference's decisions (render.comp:78 decided on the alpha cut, render.comp:82 guarded,
+ambiguous breaks resolved with the reference's arithmetic): within rounding noise of the reference's render.comp compiled for
+the CPU on any scene, BASELINE.json's bar being 1e-4.  The bit-identical mode (exp mode 2) and the opt-in fast modes are timed
+beside it as diagnostics (`frames_per_s_exact`, `frames_per_s_fast_blend`, `frames_per_s_hw_exp`) and the measured distance of
+each from the reference text on the benched frame is in `parity`.  `--ply FILE` (or GS_SCENE=FILE) benches a trained scene
+instead of the synthetic one (BASELINE configs[2]).  After the headline measurement the line also carries `other_configs`:
+configs[4] (S(6e6) at 3840x2160) and the trained-like T(6e6) at full size, time-boxed.  With N > 1 the scene blob is
+broadcast once over RCCL/xGMI and every rank renders its own camera pose (configs[3]): no per-frame collective, weak
+scaling, value = N*K frames / max-over-ranks time; the line's `rccl` block proves what the collective saw.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant pass
 and `cpu_baseline` (the oracle -- CPU restatement of the reference shaders -- on the host cores).
@@ -37,6 +41,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievabl
 VALU_PEAK = 1024 * 2.4e9 / 2
 VALU_SUSTAINED = 1024 / 1.09e-9
 MIN_TIMED_SECONDS = 0.5  # a timed region shorter than this is repeated and the median batch reported
+# the blend's modes (gs_set_exp_mode, gs_set_blend_contraction).  "default" is the library's: the guarded v_exp_f32
+MODES = {"default": (3, False), "exact": (2, False), "fast": (0, True), "hw_exp": (1, True)}
+BLEND_TEXT = {"default": "library default (exp mode 3): v_exp_f32 with the reference's decisions -- render.comp:78 decided on the alpha cut, "
+                         "render.comp:82 guarded, ambiguous breaks resolved with the reference's arithmetic; render.comp:66,87 uncontracted; "
+                         "within rounding noise of the reference text compiled for the CPU (BASELINE's bar: 1e-4)",
+              "exact": "bit-identical (exp mode 2): render.comp:66,87 uncontracted, exp = libm's expf restated in binary64",
+              "fast": "opt-in fast: polynomial exp + the three FMA contractions GLSL permits",
+              "hw_exp": "opt-in fastest: v_exp_f32 + contractions, unguarded"}
 
 
 def workload_key(n, w, h, kind):
@@ -44,8 +56,11 @@ def workload_key(n, w, h, kind):
     return f"{kind}({n})@{w}x{h}"
 
 
-def workload_name(n, w, h, world, kind="S"):
+def workload_name(n, w, h, world, kind="S", ply=None):
     """Which BASELINE.json config the arguments are, or what they are when they are none of them."""
+    if ply:
+        return (f"PLY {os.path.basename(ply)}: {n} Gaussians, {w}x{h}, degree-3 SH, one camera pose per GPU (a trained scene given at "
+                "run time: BASELINE configs[2] when it is the Mip-NeRF360 garden file)")
     base = f"{kind}({n}) synthetic Gaussians, {w}x{h}, degree-3 SH, one camera pose per GPU"
     if kind == "T":
         return base + (" (trained-scene statistics: needles and discs, clustered positions, bimodal opacity -- synth.py; "
@@ -105,10 +120,15 @@ def main():
     ap.add_argument("--bgra8", action="store_true", help="also write the B8G8R8A8_UNORM image")
     ap.add_argument("--bgra8-only", action="store_true",
                     help="write ONLY the B8G8R8A8_UNORM image -- the reference's actual target (render.comp:98, Swapchain.cpp:22-28)")
+    ap.add_argument("--exact", action="store_true",
+                    help="the bit-identical blend (exp mode 2: libm's expf restated in binary64) as the benched mode")
     ap.add_argument("--fast-blend", action="store_true",
                     help="opt-in fast blend as the benched mode: polynomial exp + the FMA contractions GLSL permits")
     ap.add_argument("--hw-exp", action="store_true", help="opt-in: the hardware's v_exp_f32 + contractions as the benched mode")
     ap.add_argument("--sh16", action="store_true", help="opt-in binary16 SH storage (gs_scene_quantize_sh)")
+    ap.add_argument("--ply", default=os.environ.get("GS_SCENE", ""),
+                    help="bench this PLY (a trained scene, BASELINE configs[2]) instead of the synthetic one; also GS_SCENE=FILE")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` block (configs[4] and T(6e6) after the headline)")
     ap.add_argument("--dump-frames", default="", help="directory: every rank saves the frame of its pose (frame_rank<r>.npy) after the timed region")
     args = ap.parse_args()
 
@@ -133,11 +153,22 @@ def main():
     pkg = entry.load_package()
     n, w, h = args.gaussians, args.width, args.height
 
-    # ---- scene: built on rank 0, broadcast as one packed SoA blob (59 floats / Gaussian) ----
+    # ---- scene: built (or loaded: --ply / GS_SCENE) on rank 0, broadcast as one packed SoA blob (59 floats / Gaussian) ----
+    if args.ply:  # a trained scene given at run time (BASELINE configs[2]): its size comes from the file
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        scene0 = None
+        if rank == 0:
+            scene0 = pkg.Scene.load_ply(args.ply, device=local_rank)  # GSScene::load (GSScene.cpp:26-68)
+            cnt[0] = scene0.num_vertices()
+        if world > 1:
+            dist.broadcast(cnt, src=0)
+        n = int(cnt.item())
     blob = torch.empty(pkg.dist.blob_floats(n), dtype=torch.float32, device=dev)
     if rank == 0:
-        rec = pkg.synth.synth_records(n, seed=0, kind=args.scene)
-        scene0 = pkg.Scene.from_records(rec, device=local_rank)  # GSScene::load path (activations on host)
+        if not args.ply:
+            rec = pkg.synth.synth_records(n, seed=0, kind=args.scene)
+            scene0 = pkg.Scene.from_records(rec, device=local_rank)  # GSScene::load path (activations on host)
+            del rec
         src, floats = scene0.blob()
         assert floats == blob.numel()
         hip = ctypes.CDLL("libamdhip64.so")
@@ -145,16 +176,18 @@ def main():
                            ctypes.c_int(3))  # hipMemcpyDeviceToDevice
         assert rc == 0
         scene0.close()
-        del rec
+    torch.cuda.synchronize()
+    t_bc = time.perf_counter()
     pkg.dist.broadcast_blob(blob, src=0)  # RCCL over xGMI; no-op at world == 1
     torch.cuda.synchronize()
+    broadcast_ms = 1e3 * (time.perf_counter() - t_bc)
+    rccl = rccl_evidence(torch, dist, dev, blob, rank, world, broadcast_ms) if world > 1 else None
     scene = pkg.Scene.from_device_blob(blob.data_ptr(), n, device=local_rank, keepalive=blob)
     if args.sh16:
         scene.quantize_sh()
     rend = pkg.Renderer(scene)
     rend.set_frames_in_flight(args.frames_in_flight)
-    MODES = {"default": (2, False), "fast": (0, True), "hw_exp": (1, True)}  # (gs_set_exp_mode, gs_set_blend_contraction)
-    mode = "hw_exp" if args.hw_exp else ("fast" if args.fast_blend else "default")
+    mode = "hw_exp" if args.hw_exp else ("fast" if args.fast_blend else ("exact" if args.exact else "default"))
 
     def set_mode(m):
         rend.set_exp_mode(MODES[m][0])
@@ -183,8 +216,8 @@ def main():
         submit(i)
     sync_all()
     # the W warm-up steps above are the contract's; the clocks of an idle chip need longer than a few milliseconds to
-    # come up (round 2: the first timed batch ran at a ninth of the median), so untimed K-step batches follow until two
-    # consecutive ones agree within 10 % (every rank runs the same count: the decision is made on the max over ranks)
+    # come up (round 2: the first timed batch ran at a ninth of the median), so untimed K-step batches follow until three
+    # consecutive ones agree within 5 % (every rank runs the same count: the decision is made on the max over ranks)
     prev, stable = None, 0
     for _ in range(40):
         sync_all()
@@ -214,6 +247,7 @@ def main():
         rend.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        own_s.append(dt)  # this rank's own wall time of the batch
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,6 +258,7 @@ def main():
     # K frames of this workload take a few milliseconds: one such region is at the mercy of a single scheduling
     # hiccup.  The K-frame batch is therefore repeated until >= MIN_TIMED_SECONDS have been timed (every rank takes
     # the same count: it is derived from the max-over-ranks time of the first batch) and the MEDIAN batch is reported.
+    own_s = []
     batch_s = [timed_batch()]
     repeats = max(1, min(200, int(math.ceil(MIN_TIMED_SECONDS / max(batch_s[0], 1e-6)))))
     for _ in range(repeats - 1):
@@ -260,17 +295,33 @@ def main():
             best.append(args.steps / (time.perf_counter() - ta))
         return float(np.median(best))
     alt = {m: (mode_fps(m) if m != mode else None) for m in MODES}
-    # the benched frame in the default and in the fast mode, for the parity block (compared with the reference text in
-    # the cpu_baseline leg, where that image exists anyway)
+    # the benched frame in every mode, for the parity block (compared with the reference text in the cpu_baseline leg, where
+    # that image exists anyway), and what the guard of the default mode did on it
     frames_for_parity = {}
+    set_mode("default")
+    rend.set_frames_in_flight(1)
+    rend.render_host(u)
+    gst = rend.stats()
+    guard = {"break_decisions_resolved_exactly": int(gst.blend_resolved), "quadrants_rerendered_exactly": int(gst.blend_redo),
+             "quadrants": ((w + 7) // 8) * ((h + 7) // 8),
+             "what": "render.comp:83 decisions that fell inside the guard's proven window around 1e-4 and were taken from an exact "
+                     "per-pixel replay; 8x8-pixel quadrants the fast pass abandoned and re-rendered with exp mode 2's arithmetic"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        for m in ("default", "fast", "hw_exp"):
+        for m in MODES:
             set_mode(m)
             frames_for_parity[m] = rend.render_host(u)[0]
     set_mode(mode)
+    rend.set_frames_in_flight(args.frames_in_flight)
     if args.dump_frames:  # tests: every rank's pose against the checker (tests/test_gpu_dist.py)
         os.makedirs(args.dump_frames, exist_ok=True)
         np.save(os.path.join(args.dump_frames, f"frame_rank{rank}.npy"), rend.render_host(u)[0])
+    # every rank's own rate over the timed batches (its frames / its own wall time, before the max over ranks)
+    rank_fps = None
+    if world > 1:
+        mine = torch.tensor([args.steps / float(np.median(own_s))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_fps = [round(float(t.item()), 2) for t in allr]
     if rank == 0:
         fps = world * args.steps / elapsed
         T = ((w + 15) // 16) * ((h + 15) // 16)
@@ -304,11 +355,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload_name(n, w, h, world, args.scene), "scene": args.scene,
-                       "blend": {"default": "reference-exact: render.comp:66,87 uncontracted, exp = libm's expf restated in binary64 "
-                                            "(bit-identical to the reference text compiled for the CPU)",
-                                 "fast": "opt-in fast: polynomial exp + the three FMA contractions GLSL permits",
-                                 "hw_exp": "opt-in fastest: v_exp_f32 + contractions"}[mode],
+            "config": {"workload": workload_name(n, w, h, world, args.scene, args.ply), "scene": "ply" if args.ply else args.scene,
+                       "blend": BLEND_TEXT[mode], "blend_guard": guard,
                        "gaussians": int(st.num_gaussians), "visible": int(st.num_visible),
                        "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries), "tiles": T, "output": "bgra8" if args.bgra8_only else ("rgba32f" + ("+bgra8" if args.bgra8 else "")),
                        "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}",
@@ -320,26 +368,41 @@ def main():
             "timed": {"batches": len(batch_s), "seconds": round(float(np.sum(batch_s)), 4),
                       "batch_ms": {"min": round(1e3 * min(batch_s), 4), "median": round(1e3 * elapsed, 4),
                                    "max": round(1e3 * max(batch_s), 4), "each": [round(1e3 * b, 2) for b in batch_s]},
-                      "spread": round(spread, 4) if spread is not None else None},
-            # distribution of the per-frame time over the timed region (median + p5/p95), rank 0
-            "frame_ms": ({"p5": round(float(np.percentile(intervals, 5)), 4), "p50": round(float(np.percentile(intervals, 50)), 4),
-                          "p95": round(float(np.percentile(intervals, 95)), 4), "n": int(len(intervals))}
-                         if len(intervals) else None),
+                      "spread": round(spread, 4) if spread is not None else None,
+                      # batches beyond 1.5 x the median (index, ms): mid-run hiccups the median hides and the line records
+                      "outliers": [[i, round(1e3 * b, 2)] for i, b in enumerate(batch_s) if b > 1.5 * elapsed]},
+            # intervals between the COMPLETIONS of consecutive frames (GPU timestamps), rank 0.  With frames in flight on several
+            # streams completions come in bursts and out of order: this is what a consumer polling for finished frames sees, NOT a
+            # per-frame time -- ms_per_step is that
+            "completion_interval_ms": ({"p5": round(float(np.percentile(intervals, 5)), 4), "p50": round(float(np.percentile(intervals, 50)), 4),
+                                        "p95": round(float(np.percentile(intervals, 95)), 4), "n": int(len(intervals))}
+                                       if len(intervals) else None),
             "gpu_ms_per_frame": round(sums.ms_total / max(frames, 1), 4),
             "frames_per_s_one_in_flight": round(serial_fps, 2),  # diagnostic: one frame at a time (latency-bound)
             # diagnostics, this rank: the same region in the other blend modes (None = the benched one)
-            "frames_per_s_strict": round(alt["default"], 2) if alt["default"] else (round(fps / world, 2) if mode == "default" else None),
+            "frames_per_s_default": round(alt["default"], 2) if alt["default"] else None,
+            "frames_per_s_exact": round(alt["exact"], 2) if alt["exact"] else None,   # the bit-identical mode (round 3's default)
             "frames_per_s_fast_blend": round(alt["fast"], 2) if alt["fast"] else None,
             "frames_per_s_hw_exp": round(alt["hw_exp"], 2) if alt["hw_exp"] else None,
             "passes": per_pass,
             "passes_serial_ms": {k: round(getattr(ssum, "ms_" + k) / max(sframes, 1), 4) for k in names + ["total"]},
-            "roofline": roofline(pkg, dom, workload_key(n, w, h, args.scene), MODES[mode], nbytes[dom], ms[dom], serial[dom],
-                                 1e3 * elapsed / args.steps),
+            "roofline": roofline(pkg, dom, workload_key(n, w, h, "ply" if args.ply else args.scene), MODES[mode], nbytes[dom], ms[dom],
+                                 serial[dom], 1e3 * elapsed / args.steps),
         }
+        if world > 1:
+            result["rccl"] = dict(rccl or {}, per_rank_frames_per_s=rank_fps,
+                                  slowest_rank=int(np.argmin(rank_fps)) if rank_fps else None)
         if args.bgra8_only:
             result["passes"]["render"]["alg_MB"] = round((nbytes["render"] - 12 * w * h) / 1e6, 2)  # 4 B per pixel out, not 16
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
-            result["cpu_baseline"], result["parity"] = cpu_baseline(n, w, h, args.scene, frames_for_parity)
+            result["cpu_baseline"], result["parity"] = cpu_baseline(n, w, h, args.scene, frames_for_parity, ply=args.ply)
+        # the other BASELINE configs a single command can show (verdict r3 item 8): after the headline, its renderer released
+        if world == 1 and not args.no_other_configs and not args.ply and (n, w, h, args.scene) == (1_000_000, 1920, 1080, "S"):
+            rend.close()
+            scene.close()
+            del blob, outs, outs8
+            torch.cuda.empty_cache()
+            result["other_configs"] = other_configs(pkg, torch, dev, local_rank, args, float(os.environ.get("GS_OTHER_CONFIGS_SECONDS", 75)))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -350,8 +413,126 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 
 
 def blend_kernel_name(mode):
-    """The k_blend instantiation a (exp mode, contraction) pair launches, as rocprofv3 prints it."""
-    return f"k_blend<{mode[0]}, {'true' if mode[1] else 'false'}>"
+    """The k_blend<EXP, CONTRACT, GUARD> instantiation a (exp mode, contraction) pair launches, as rocprofv3 prints it."""
+    exp, contract = mode
+    if exp == 3:  # the guarded v_exp_f32 (with the contractions on there is nothing to guard: mode 1)
+        return "k_blend<1, false, true>" if not contract else "k_blend<1, true, false>"
+    return f"k_blend<{exp}, {'true' if contract else 'false'}, false>"
+
+
+def rccl_evidence(torch, dist, dev, blob, rank, world, broadcast_ms):
+    """What the collective actually saw (verdict r3 item 7: nobody has watched RCCL run with N > 1): an all-reduce of ones
+    over the group (= the number of ranks that took part), the backend and its version, the broadcast's wall time and size,
+    and a checksum of every rank's copy of the blob against rank 0's."""
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(ones)
+    # checksum of the received blob: sum of its bit patterns (int64, wraps identically everywhere)
+    chk = blob.view(torch.int32).to(torch.int64).sum().reshape(1)
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    sums = [int(t.item()) for t in allc]
+    tmax = torch.tensor([broadcast_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    backend = dist.get_backend()
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001 -- evidence only
+            version = f"unavailable: {e}"
+    mb = blob.numel() * 4 / 1e6
+    return {"ranks": int(round(float(ones.item()))), "world_size": world, "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
+            "version": version, "blob_MB": round(mb, 1), "broadcast_ms": round(float(tmax.item()), 3),
+            "broadcast_GBps": round(mb / 1e3 / (float(tmax.item()) * 1e-3), 1) if tmax.item() > 0 else None,
+            "blob_checksums_equal_rank0": all(c == sums[0] for c in sums), "blob_checksum": sums[0]}
+
+
+def other_configs(pkg, torch, dev, device, args, budget_s):
+    """BASELINE configs[4] -- S(6e6) at 3840x2160 -- and the trained-like stand-in for configs[2] -- T(6e6) at 1920x1080 -- at
+    their full sizes, in the same command as the headline: frames/s in the default mode (3 frames in flight, RGBA32F in HBM),
+    serial per-pass ms, the exact mode's rate, and parity: the exact mode's frame bit for bit and the default mode's max abs
+    against the CPU checker (oracle port, which tests pin to the reference text) on the same scene.  Time-boxed: a config
+    that does not fit in what is left of `budget_s` is reported as skipped."""
+    import concurrent.futures as cf
+    oracle = entry.load_oracle()
+    t_start = time.perf_counter()
+    out = {}
+    for name, (n, w, h, kind, label) in {"E": (6_000_000, 3840, 2160, "S", "BASELINE configs[4]"),
+                                          "T": (6_000_000, 1920, 1080, "T", "trained-scene statistics; stand-in for BASELINE configs[2]")}.items():
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 25:
+            out[name] = {"skipped": f"{left:.0f} s left of the {budget_s:.0f} s box"}
+            continue
+        t0 = time.perf_counter()
+        # the scene, generated in slices on a thread pool (numpy releases the GIL in its array kernels; bit-identical to one call)
+        chunk = 250_000
+        with cf.ThreadPoolExecutor(min(24, os.cpu_count() or 8)) as ex:
+            parts = list(ex.map(lambda s0: pkg.synth.synth_records(min(chunk, n - s0), seed=0, kind=kind, n_total=n, start=s0),
+                                range(0, n, chunk)))
+        rec = np.concatenate(parts)
+        del parts
+        t_gen = time.perf_counter() - t0
+        scene = pkg.Scene.from_records(rec, device=device)
+        rend = pkg.Renderer(scene)
+        u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+        fif = args.frames_in_flight
+        outs = [torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(fif)]
+
+        def rate(mode, frames):
+            rend.set_exp_mode(MODES[mode][0])
+            rend.set_blend_contraction(MODES[mode][1])
+            rend.set_frames_in_flight(fif)
+            for i in range(max(10, frames // 4)):
+                rend.render(u, outs[i % fif].data_ptr(), 0)
+            rend.synchronize()
+            best = []
+            for _ in range(3):
+                ta = time.perf_counter()
+                for i in range(frames):
+                    rend.render(u, outs[i % fif].data_ptr(), 0)
+                rend.synchronize()
+                best.append(frames / (time.perf_counter() - ta))
+            return float(np.median(best))
+        fps = rate("default", 120)
+        fps_exact = rate("exact", 120)
+        rend.set_exp_mode(MODES["default"][0])
+        rend.set_frames_in_flight(1)
+        rend.timing_totals(reset=True)
+        for i in range(40):
+            rend.render(u, outs[0].data_ptr(), 0)
+        rend.synchronize()
+        ssum, sframes = rend.timing_totals(reset=True)
+        img_default = rend.render_host(u)[0]
+        st = rend.stats()
+        rend.set_exp_mode(MODES["exact"][0])
+        img_exact = rend.render_host(u)[0]
+        entry_ = {"workload": workload_name(n, w, h, 1, kind), "label": label, "frames_per_s": round(fps, 2), "frames_per_s_exact": round(fps_exact, 2),
+                  "gaussians": int(st.num_gaussians), "visible": int(st.num_visible), "instances": int(st.num_instances),
+                  "sort_level": int(st.sort_level), "bin_tiles": int(st.bin_tiles), "frames_in_flight": fif,
+                  "passes_serial_ms": {k: round(getattr(ssum, "ms_" + k) / max(sframes, 1), 4)
+                                       for k in ("preprocess", "prefix_sum", "preprocess_sort", "sort", "tile_boundary", "render", "total")},
+                  "blend_guard": {"break_decisions_resolved_exactly": int(st.blend_resolved), "quadrants_rerendered_exactly": int(st.blend_redo)},
+                  "scene_generation_s": round(t_gen, 1)}
+        rend.close()
+        scene.close()
+        del outs
+        torch.cuda.empty_cache()
+        if budget_s - (time.perf_counter() - t_start) > 12:  # parity against the CPU checker on this very scene
+            verts = oracle.activate_records(rec)
+            del rec
+            ref_img, _ = oracle.render_frame(verts, oracle.cov3d(verts), oracle.camera_uniforms(oracle.default_camera(), w, h), want_image=True)
+            d = np.abs(img_default[..., :3].astype(np.float64) - ref_img[..., :3])
+            entry_["parity"] = {"against": "oracle port, default (reference) reading -- pinned bit for bit to the reference text by tests/test_oracle_vs_ref.py",
+                                "exact_mode_bit_identical": bool(np.array_equal(img_exact.view(np.uint32), ref_img.view(np.uint32))),
+                                "default_mode_max_abs": float(d.max()), "default_mode_pixels_above_1e-5": int((d.max(axis=2) > 1e-5).sum())}
+            del verts, ref_img
+        else:
+            del rec
+            entry_["parity"] = {"skipped": "time box"}
+        entry_["seconds"] = round(time.perf_counter() - t0, 1)
+        out[name] = entry_
+    out["seconds"] = round(time.perf_counter() - t_start, 1)
+    return out
 
 
 def committed_counters(pkg, pass_name, wkey, mode):
@@ -400,15 +581,19 @@ def committed_blend_work(wkey):
 
 
 def roofline(pkg, pass_name, wkey, mode, alg_bytes, ms_timed, ms_serial, ms_per_frame):
-    """Roofline of the dominant kernel.  k_blend is bound by FP32 VALU issue, not by HBM.
-    `frac` is computed on the wall time of ONE FRAME in the timed region (ms_per_step): with frames in flight the
-    HIP-event span of a launch overlaps the other frames' kernels and spans are not additive, so a launch's
-    instructions / bytes over the frame time is the rate the chip sustains for this kernel alongside everything else a
-    frame needs -- and it follows from profiles/ by division (`wave_insts` / `ms_per_frame`).  `one_in_flight` is the
-    same launch with the GPU to itself.  Three views: VALU issue (SQ_INSTS_VALU of this very library, when the committed
-    counters belong to it), SURVEY 8d's flops (22 per (pixel, entry) pair the reference's loop walks) against the FP32
-    vector peak, and HBM (algorithmic bytes against 8 TB/s)."""
-    kernel = {"render": "k_blend"}.get(pass_name, pass_name)
+    """Roofline of the dominant kernel, on the wall time of ONE FRAME in the timed region (ms_per_step): with frames in flight
+    the HIP-event span of a launch overlaps the other frames' kernels and spans are not additive, so work / frame time is
+    the rate the chip sustains for this kernel alongside everything else a frame needs.  `one_in_flight` = the same launch
+    with the GPU to itself.
+
+    For k_blend (FP32 VALU-bound) the headline `frac` is SURVEY 8d's FLOP VIEW: 22 flop per (pixel,
+    entry) pair the REFERENCE's loop walks on this workload (profiles/rNN_blend_work.json: a property of the scene, camera and
+    resolution, not of these kernels) over the frame time, against the 157.3 TFLOP/s FP32 vector peak -- a figure a slower
+    kernel cannot raise.  Beside it: `valu_issue`, the occupancy of the VALU issue slots (SQ_INSTS_VALU of this very library's
+    kernel, from the committed counter run, over the frame time against 1228.8 G wave64-instructions/s) -- its numerator is
+    the kernel's OWN instruction count, so it says how busy the pipe is, not how much useful work gets done -- and `hbm`, the
+    algorithmic bytes against 8 TB/s.  Other kernels (k_preprocess at the 6 M configs) get the HBM view as the headline."""
+    kernel = blend_kernel_name(mode) if pass_name == "render" else pass_name
 
     def rate(x, ms):
         return x / (ms * 1e-3) if ms and ms > 0 else None
@@ -417,46 +602,51 @@ def roofline(pkg, pass_name, wkey, mode, alg_bytes, ms_timed, ms_serial, ms_per_
            "frac": round(gb["frame"] / HBM_PEAK_GBS, 4) if gb["frame"] else None, "algorithmic_bytes": int(alg_bytes),
            "one_in_flight": {"ms": round(ms_serial, 4), "achieved": round(gb["serial"], 1) if gb["serial"] else None,
                              "frac": round(gb["serial"] / HBM_PEAK_GBS, 4) if gb["serial"] else None}}
-    flops_view = None
+    c, why = committed_counters(pkg, pass_name, wkey, mode)
+    common = {"kernel": c["kernel"] if c else kernel,
+              "basis": "per_frame_time: one launch over ms_per_step (frames in flight overlap: spans are not additive)",
+              "ms_per_frame": round(ms_per_frame, 4), "span_ms_in_timed_region": round(ms_timed, 4),
+              "algorithmic_bytes": int(alg_bytes), "traffic": c["traffic"] if c else None,
+              "counters": c["file"] if c else None}
+    valu_issue = None
+    if c is not None and pass_name == "render" and ms_per_frame > 0:
+        insts = c["valu_wave_insts"]
+        r, r1 = rate(insts, ms_per_frame), rate(insts, ms_serial)
+        valu_issue = {"achieved": round(r / 1e9, 2), "peak": round(VALU_PEAK / 1e9, 2), "unit": "G wave64-inst/s", "frac": round(r / VALU_PEAK, 4),
+                      "wave_insts": insts, "one_in_flight_frac": round(r1 / VALU_PEAK, 4) if r1 else None,
+                      "sustained": {"peak": round(VALU_SUSTAINED / 1e9, 2), "frac": round(r / VALU_SUSTAINED, 4),
+                                    "what": "issue rate tools/ubench/valu_rate.hip measures on this chip under dense VALU load (~1.85 GHz)"},
+                      "note": "occupancy of the VALU issue slots: the numerator is this kernel's own SQ_INSTS_VALU, so a kernel that spends "
+                              "more instructions on the same frame scores HIGHER here -- read `frac` (the flop view) for work done"}
     work = committed_blend_work(wkey) if pass_name == "render" else None
-    if work:
+    if work and ms_per_frame > 0:
         fl = 22.0 * work["walked_pairs"]
         tf, tf1 = rate(fl / 1e12, ms_per_frame), rate(fl / 1e12, ms_serial)
-        flops_view = {"walked_pairs": work["walked_pairs"], "contributing_pairs": work["contributing_pairs"],
-                      "flop_per_pair": 22, "achieved": round(tf, 2) if tf else None, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": round(tf / FP32_PEAK_TFLOPS, 4) if tf else None,
-                      "one_in_flight_frac": round(tf1 / FP32_PEAK_TFLOPS, 4) if tf1 else None, "counts": work["file"]}
-    c, why = committed_counters(pkg, pass_name, wkey, mode)
-    common = {"kernel": kernel, "basis": "per_frame_time: one launch over ms_per_step (frames in flight overlap: spans are not additive)",
-              "ms_per_frame": round(ms_per_frame, 4), "span_ms_in_timed_region": round(ms_timed, 4),
-              "algorithmic_bytes": int(alg_bytes), "flops_view": flops_view}
-    if c is None or pass_name != "render" or not ms_per_frame > 0:
-        return dict(common, bound="hbm", achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac"],
-                    traffic=c["traffic"] if c else None, one_in_flight=hbm["one_in_flight"],
-                    note=("HBM view" + (f": {why}" if why else "") + "; for k_blend the binding roof is FP32 VALU issue "
-                          "(DESIGN.md section 4) and needs SQ_INSTS_VALU of this library (tools/profile_lite.sh)"))
-    insts = c["valu_wave_insts"]
-    r, r1 = rate(insts, ms_per_frame), rate(insts, ms_serial)
-    return dict(common, kernel=c["kernel"], bound="valu", achieved=round(r / 1e9, 2), peak=round(VALU_PEAK / 1e9, 2),
-                unit="G wave64-inst/s", frac=round(r / VALU_PEAK, 4), traffic=c["traffic"], wave_insts=insts, counters=c["file"],
-                sustained={"peak": round(VALU_SUSTAINED / 1e9, 2), "frac": round(r / VALU_SUSTAINED, 4),
-                           "what": "issue rate tools/ubench/valu_rate.hip measures on this chip under dense VALU load (~1.85 GHz)"},
-                one_in_flight={"ms": round(ms_serial, 4), "frac": round(r1 / VALU_PEAK, 4) if r1 else None,
-                               "frac_of_sustained": round(r1 / VALU_SUSTAINED, 4) if r1 else None},
-                hbm=hbm,
-                note="wave_insts counts every VALU instruction as one issue slot; the default blend's nine binary64 operations per "
-                     "pair occupy two each (half rate), so the issue pipe is busier than frac says")
+        return dict(common, bound="valu", achieved=round(tf, 2), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / FP32_PEAK_TFLOPS, 4),
+                    what="SURVEY 8d flop view: 22 flop x the (pixel, entry) pairs the reference's loop walks on this workload, per frame time, "
+                         "against the FP32 vector peak (MFMA is not used: there is no dense contraction on this path)",
+                    walked_pairs=work["walked_pairs"], contributing_pairs=work["contributing_pairs"], flop_per_pair=22, counts=work["file"],
+                    one_in_flight={"ms": round(ms_serial, 4), "achieved": round(tf1, 2) if tf1 else None,
+                                   "frac": round(tf1 / FP32_PEAK_TFLOPS, 4) if tf1 else None},
+                    valu_issue=valu_issue, valu_issue_note=None if valu_issue else why, hbm=hbm)
+    return dict(common, bound="hbm", achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac"],
+                one_in_flight=hbm["one_in_flight"], valu_issue=valu_issue,
+                note=("HBM view" + (f": {why}" if why else "") + ("; for k_blend the binding roof is FP32 VALU issue (DESIGN.md section 4): the "
+                      "flop view needs the workload's walked-pair count (tools/blend_stats.py -> profiles/rNN_blend_work.json)"
+                      if pass_name == "render" else "")))
 
 
-def cpu_baseline(n, w, h, kind="S", gpu_frames=None):
+def cpu_baseline(n, w, h, kind="S", gpu_frames=None, ply=None):
     """The oracle (CPU restatement of the reference shaders, all host cores via OpenMP) on one frame of
     the same workload -- a bounded sample (about 10-30 s of CPU work).  Baseline only.  Returns (cpu_baseline, parity):
     parity = the GPU's frames of this workload (gpu_frames: mode -> image) against the reference text's frame (or the
     port's, which tests pin to it bit for bit, when oracle/_ref did not travel)."""
     oracle = entry.load_oracle()
     pkg = entry.load_package()
-    rec = pkg.synth.synth_records(n, seed=0, kind=kind)
-    verts = oracle.activate_records(rec)
+    if ply:
+        verts = oracle.load_ply(ply)  # the checker's own reader + activation (GSScene.cpp:26-68 restated)
+    else:
+        verts = oracle.activate_records(pkg.synth.synth_records(n, seed=0, kind=kind))
     cov = oracle.cov3d(verts)
     u = oracle.camera_uniforms(oracle.default_camera(), w, h)
     ref_img, _ = oracle.render_frame(verts, cov, u, want_image=True)  # warm-up (scalar blend = the parity checker)

@@ -283,6 +283,20 @@ int gs_dist_broadcast_scene(gs_dist* d, gs_scene* mine /* root only */, int root
  * broadcast from `mine`), which it owns beside `mine` -- every rank then runs the same receiving code. */
 #define GS_DIST_COPY_ON_ROOT 1u
 int gs_dist_broadcast_scene_ex(gs_dist* d, gs_scene* mine /* root only */, int root, unsigned flags, gs_scene** out);
+/* Evidence that the collective saw every rank and that every rank holds the root's scene (collective: every rank calls it
+ * after gs_dist_broadcast_scene): `ranks` = an ncclAllReduce(sum) of one per rank, `checksums_equal` = the ncclAllReduce min
+ * and max of each rank's checksum of its replica (the sum of the blob's 32-bit patterns) coincide with this rank's,
+ * `broadcast_ms` / `broadcast_bytes` = this rank's wall time and payload of its last scene broadcast. */
+typedef struct {
+    uint64_t ranks;            /* ranks that took part in the all-reduce (must equal world) */
+    uint64_t world;
+    uint64_t checksum;         /* of this rank's replica */
+    uint64_t broadcast_bytes;
+    double broadcast_ms;
+    uint32_t checksums_equal;  /* 1: every rank's replica has this checksum */
+    uint32_t rccl_version;     /* ncclGetVersion */
+} gs_dist_report;
+int gs_dist_verify(gs_dist* d, const gs_scene* scene, gs_dist_report* out);
 void gs_dist_destroy(gs_dist* d);
 
 #ifdef __cplusplus

@@ -24,7 +24,19 @@ def pkg():
 
 @pytest.fixture(scope="session")
 def oracle():
-    return entry.load_oracle()
+    """The CPU checker.  Its exp() restates glibc's expf (x86-64 FMA build, glibc >= 2.27); the bitwise image tests compare with
+    the reference text compiled against THIS HOST's libm.  On a host whose libm evaluates expf differently (no FMA, another libc)
+    the two would disagree for reasons that have nothing to do with the kernels: a sample of the pin is taken here once, and
+    helpers.assert_images_identical turns a bitwise image mismatch into an xfail with that explanation instead of a failure
+    (tests/test_expf_libm.py still runs the exhaustive pin and fails loudly)."""
+    o = entry.load_oracle()
+    import helpers
+    bad = 0
+    for first in (0x80000000, 0xBF000000, 0xC0A00000, 0xC2A00000):  # -0.., -0.5.., -5.., -80..: 4 x 2^20 values
+        n, _ = o.expf_libm_mismatches(first, 1 << 20)
+        bad += n
+    helpers.HOST_LIBM_MISMATCHES = bad
+    return o
 
 
 @pytest.fixture(scope="session")

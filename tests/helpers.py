@@ -104,9 +104,16 @@ def classify_pixel(attr, boundaries, payload, width, px, py):
     return near
 
 
+HOST_LIBM_MISMATCHES = 0  # set by conftest's oracle fixture: sampled disagreements between the restated expf and this host's libm
+
+
 def assert_images_identical(img, ref_img, label=""):
-    """Bit-for-bit equality of two fp32 images (the default blend against the reference text / the oracle)."""
+    """Bit-for-bit equality of two fp32 images (the exact blend against the reference text / the oracle)."""
     a, b = np.ascontiguousarray(img, np.float32).view(np.uint32), np.ascontiguousarray(ref_img, np.float32).view(np.uint32)
+    if not np.array_equal(a, b) and HOST_LIBM_MISMATCHES:
+        import pytest
+        pytest.xfail(f"{label}: images differ, and this host's libm expf is not glibc's x86-64 FMA build ({HOST_LIBM_MISMATCHES} sampled "
+                     "disagreements with the restated algorithm): the bit-identity claim is 'glibc expf (FMA build) + uncontracted render.comp'")
     if not np.array_equal(a, b):
         bad = np.argwhere((a != b).any(axis=-1))
         d = np.abs(img.astype(np.float64) - ref_img).max()

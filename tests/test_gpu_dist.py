@@ -82,6 +82,12 @@ def test_pose_shard_host_renders_every_pose(pkg, oracle, gpu, tmp_path):
     out = subprocess.run([exe, ply, str(w), str(h), str(poses), str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr + out.stdout
     assert f"{poses} of {poses} poses" in out.stdout
+    # gs_dist_verify's evidence, printed by the native host too (one rank here: RCCL refuses two ranks on one device): the
+    # all-reduce saw one rank, the replica's checksum equals itself, the broadcast was timed and sized
+    import json
+    rep = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"rccl"')][0])["rccl"]
+    assert rep["ranks"] == 1 and rep["world_size"] == 1 and rep["blob_checksums_equal"] is True and rep["version"] > 20000
+    assert rep["blob_MB"] == round(pkg.dist.blob_floats(6000) * 4 / 1e6, 1) and rep["broadcast_ms"] > 0
     verts = oracle.activate_records(rec)
     for k in range(poses):
         cam = oracle.default_camera(rotation=pkg.dist.pose_quaternion(k))
@@ -105,13 +111,20 @@ def test_bench_two_ranks_on_one_gpu(pkg, oracle, gpu, tmp_path):
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-           "--gaussians", str(n), "--width", str(w), "--height", str(h), "--dump-frames", str(tmp_path)]
+           "--gaussians", str(n), "--width", str(w), "--height", str(h), "--dump-frames", str(tmp_path), "--exact"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["gaussians"] == n
     assert abs(line["value"] - 2 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-3  # whole-job frames: both ranks' K steps
-    assert "cpu_baseline" not in line  # rank 0 at N = 1 only
+    assert "cpu_baseline" not in line and "other_configs" not in line  # rank 0 at N = 1 only
+    # what the collective saw (bench.py: rccl_evidence): every rank took part, every rank holds rank 0's blob, and the line
+    # carries each rank's own rate (the driver's 8-GPU run prints the same block over RCCL)
+    r = line["rccl"]
+    assert r["ranks"] == 2 and r["world_size"] == 2 and r["backend"].startswith("gloo") and r["blob_checksums_equal_rank0"] is True
+    assert r["blob_MB"] == round(pkg.dist.blob_floats(n) * 4 / 1e6, 1) and r["broadcast_ms"] > 0
+    assert len(r["per_rank_frames_per_s"]) == 2 and all(x > 0 for x in r["per_rank_frames_per_s"]) and r["slowest_rank"] in (0, 1)
+    assert line["value"] <= sum(r["per_rank_frames_per_s"]) * 1.001  # the job's rate is bounded by its slowest rank
     verts = oracle.activate_records(pkg.synth.synth_records(n, seed=0, kind="S"))
     for rank in (0, 1):
         cam = oracle.default_camera(rotation=pkg.dist.pose_quaternion(rank))

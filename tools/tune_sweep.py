@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="1 and 3 frames in flight, twice (A/B of library builds)")
     ap.add_argument("--sh16", action="store_true")
     ap.add_argument("--scene", choices=["S", "T"], default="S")
-    ap.add_argument("--exp-mode", type=int, default=2, help="gs_set_exp_mode: 2 libm-exact (default), 0 polynomial, 1 v_exp_f32")
+    ap.add_argument("--exp-mode", type=int, default=3, help="gs_set_exp_mode: 3 guarded v_exp_f32 (default), 2 libm-exact, 0 polynomial, 1 v_exp_f32")
     ap.add_argument("--contract", type=int, default=0, help="gs_set_blend_contraction")
     ap.add_argument("--warm", type=int, default=20, help="untimed frames ahead of every configuration")
     ap.add_argument("--no-prime", action="store_true", help="skip the initial 3-in-flight run (profiled runs: only the asked configurations launch)")
