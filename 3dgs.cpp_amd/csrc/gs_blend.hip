@@ -277,7 +277,9 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
             float4 uv = slab[1][k];
             float4 bp = slab[2][k];
             // all ten floats in one LDS round trip: without this the compiler sinks the loads of o, r, g, b
-            // behind the exp() branch, where 94 % of the pairs then pay a second LDS latency
+            // behind the exp() branch, where 94 % of the pairs then pay a second LDS latency.  (Reading the NEXT pair's record
+            // while this one is evaluated -- two register sets taking turns -- was measured in round 4: 0.203 against 0.183 ms
+            // for the unguarded loop, 0.260 against 0.242 ms for the exact one: the loop is not waiting for LDS.)
             asm volatile("" : "+v"(co.w), "+v"(uv.z), "+v"(uv.w), "+v"(bp.x));
             const float dx = uv.x - fx;
             const float dy = uv.y - fy;
@@ -353,7 +355,16 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                 STAT_ADD(7, (unsigned long long)__popcll(mk) * ((base - range.x) + (uint32_t)k + 1u));
                 const bool upd = __builtin_amdgcn_inverse_ballot_w64(m2 & ~mk);
                 if (upd) {  // the accumulate runs under the exec mask: no selects
-                    if (CONTRACT) {
+                    if (GUARD) {
+                        // :87 c += color * alpha * T.  The guarded mode owes the reference its DECISIONS bit for bit (they hang on
+                        // `power` and on the T chain, both evaluated as written) and its pixels to rounding noise: the weight
+                        // alpha * T is formed once and each channel takes one fused multiply-add (4 instructions for 9; every
+                        // contribution within an ULP of the reference's, no cancellation anywhere in this sum)
+                        const float wgt = alpha * T;
+                        c0 = __builtin_fmaf(uv.z, wgt, c0);
+                        c1 = __builtin_fmaf(uv.w, wgt, c1);
+                        c2 = __builtin_fmaf(bp.x, wgt, c2);
+                    } else if (CONTRACT) {
                         c0 = __builtin_fmaf(uv.z * alpha, T, c0);  // :87  FMA
                         c1 = __builtin_fmaf(uv.w * alpha, T, c1);
                         c2 = __builtin_fmaf(bp.x * alpha, T, c2);
