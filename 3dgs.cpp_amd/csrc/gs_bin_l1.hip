@@ -353,6 +353,28 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     }
 }
 
+// Stage taps after a frame whose level 1 streamed the dense lists (k_preprocess wrote no planes): tiles_overlap, depth and the
+// tile box of every visible Gaussian rebuilt from the lists' entries (the caller zeroes `tiles` first; the frame's list lengths
+// are the words the blend left behind the counters).
+__global__ __launch_bounds__(BLOCK) void k_vis_to_planes(const uint4* __restrict__ vis, const uint32_t* __restrict__ vis_count,
+                                                         uint32_t region_slots, uint32_t* __restrict__ tiles, float* __restrict__ depth,
+                                                         ushort4* __restrict__ aabb) {
+    const uint32_t region = blockIdx.y, slot = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t count = min(vis_count[region * kVisCounterStride + 1], region_slots);
+    if (slot >= count) return;
+    const uint4 e = vis[(size_t)region * region_slots + slot];  // {id, depth bits, x0 | y0 << 16, x1 | y1 << 16}
+    const uint32_t x0 = e.z & 0xFFFFu, y0 = e.z >> 16, x1 = e.w & 0xFFFFu, y1 = e.w >> 16;
+    tiles[e.x] = (x1 - x0) * (y1 - y0);
+    depth[e.x] = __uint_as_float(e.y);
+    aabb[e.x] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+}
+void launch_vis_to_planes(const AttrView& av, uint32_t n, hipStream_t s) {
+    if (!av.vis || n == 0) return;
+    (void)hipMemsetAsync(av.tiles, 0, (size_t)n * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_vis_to_planes, dim3((av.vis_region_slots + BLOCK - 1) / BLOCK, kVisRegions), dim3(BLOCK), 0, s, av.vis, av.vis_count,
+                       av.vis_region_slots, av.tiles, av.depth, av.aabb);
+}
+
 static L1Args l1_args(const BinLaunch& b) {
     L1Args a;
     a.g = BinGrid{b.tiles_x, b.tiles_y, b.bins_x, b.bins_y, b.bin_shift, b.grid_shift};

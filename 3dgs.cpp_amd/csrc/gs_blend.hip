@@ -430,7 +430,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // the frame's completion event, which carries the system-scope release, has fired) -- no copy node in the stream
     if (host_counters && blockIdx.x == 0 && tid == 0) *host_counters = *counters;
     // ... and k_preprocess of the next frame on these buffers appends to the dense lists of visible Gaussians from zero again
-    if (vis_count && blockIdx.x == 0 && (uint32_t)tid < kVisRegions) vis_count[(uint32_t)tid * kVisCounterStride] = 0;
+    // (the counts of THIS frame stay readable in the word behind each counter: the stage taps rebuild the per-Gaussian planes from the lists)
+    if (vis_count && blockIdx.x == 0 && (uint32_t)tid < kVisRegions) {
+        vis_count[(uint32_t)tid * kVisCounterStride + 1] = vis_count[(uint32_t)tid * kVisCounterStride];
+        vis_count[(uint32_t)tid * kVisCounterStride] = 0;
+    }
     // XCD-aware, load-balanced tile order: a host-built table (gs_capi.cpp, ensure_tile_order)
     const uint32_t tile = tile_order[blockIdx.x];
     const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;

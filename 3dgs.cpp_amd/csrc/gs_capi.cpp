@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <limits>
 #include <fstream>
 #include <memory>
 #include <sstream>
@@ -112,6 +113,15 @@ struct gs_scene {
     DevBuf<float> owned_blob;
     float* blob = nullptr;  // owned_blob.p or adopted
     DevBuf<float> cov3d;
+    // The per-frame kernels may read the scene from a SECOND copy in spatial (Morton) order -- a wave's 64 Gaussians neighbours
+    // in space -- while ids, taps, the broadcast blob and the downloads keep the scene's own order (gs::SceneView::perm).
+    // Scenes of >= GS_SPATIAL_MIN Gaussians get the copy (default 4 M, where level 1 streams the dense lists: measured A/B on one
+    // box, frames bit-identical, profiles/r04_spatial_order_ab.txt: S(6e6) at 1080p +5.2 % frames/s, at 2160p +2.4 %, T(6e6) +1.8 %
+    // -- the level-1 scatter 53 -> 36 us, its records leaving a block in long runs per bin; config B -8 % with three frames in
+    // flight and +-0 one at a time: off there).  Costs a second scene (236 B / Gaussian) and a host-side sort at load.
+    DevBuf<float> spatial_blob;
+    DevBuf<uint32_t> perm;     // Gaussian j of the spatial copy = Gaussian perm[j] of the scene
+    const float* render_blob() const { return spatial_blob.p ? spatial_blob.p : blob; }
     bool unit_opacity = true;  // no opacity exceeds 1 (the sigmoid's range): what the guarded blend's bound assumes
     DevBuf<float> acut;     // the alpha cut of every Gaussian: render.comp:78 as a bound on `power`, from the opacity (gs::launch_alpha_cut)
     DevBuf<uint16_t> sh16;  // gs_scene_quantize_sh: the SH block as binary16 (preprocess reads it instead)
@@ -121,16 +131,66 @@ struct gs_scene {
         cov3d.alloc(6 * n);
         if (reinterpret_cast<uintptr_t>(blob) % 64 != 0)
             throw Error(GS_ERR_INVALID, "the scene blob must be 64-byte aligned (SH blocks are read as 16-byte vectors)");
-        gs::launch_cov3d(blob, cov3d.p, static_cast<uint32_t>(n), static_cast<uint32_t>(gs::blob_stride(n)), nullptr);
+        make_spatial_copy();
+        gs::launch_cov3d(render_blob(), cov3d.p, static_cast<uint32_t>(n), static_cast<uint32_t>(gs::blob_stride(n)), nullptr);
         acut.alloc(n);
         DevBuf<uint32_t> beyond;
         beyond.alloc(1);
         HIP_CHECK(hipMemset(beyond.p, 0, sizeof(uint32_t)));
-        gs::launch_alpha_cut(blob, acut.p, static_cast<uint32_t>(n), static_cast<uint32_t>(gs::blob_stride(n)), beyond.p, nullptr);
+        gs::launch_alpha_cut(render_blob(), acut.p, static_cast<uint32_t>(n), static_cast<uint32_t>(gs::blob_stride(n)), beyond.p, nullptr);
         HIP_CHECK(hipGetLastError());
         uint32_t flag = 0;
         HIP_CHECK(hipMemcpy(&flag, beyond.p, sizeof flag, hipMemcpyDeviceToHost));  // (synchronises)
         unit_opacity = flag == 0;
+    }
+
+    // Spatial order: Morton code of the position (21 bits per axis over the scene's bounding box), ties by id.
+    void make_spatial_copy() {
+        uint64_t min_n = 4ull << 20;
+        if (const char* e = std::getenv("GS_SPATIAL_MIN")) min_n = std::strtoull(e, nullptr, 10);
+        if (n == 0 || n < min_n) return;
+        const size_t st = gs::blob_stride(n);
+        std::vector<float> pos(3 * n);
+        for (int k = 0; k < 3; ++k)
+            HIP_CHECK(hipMemcpy(pos.data() + static_cast<size_t>(k) * n, blob + static_cast<size_t>(gs::P_POS + k) * st, n * sizeof(float), hipMemcpyDeviceToHost));
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::numeric_limits<float>::infinity();
+            hi[k] = -lo[k];
+            for (uint64_t i = 0; i < n; ++i) {
+                const float v = pos[static_cast<size_t>(k) * n + i];
+                if (std::isfinite(v)) lo[k] = std::min(lo[k], v), hi[k] = std::max(hi[k], v);
+            }
+            if (!(hi[k] > lo[k])) hi[k] = lo[k] + 1.0f;
+        }
+        auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+            v &= 0x1FFFFFull;
+            v = (v | v << 32) & 0x1F00000000FFFFull;
+            v = (v | v << 16) & 0x1F0000FF0000FFull;
+            v = (v | v << 8) & 0x100F00F00F00F00Full;
+            v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+            v = (v | v << 2) & 0x1249249249249249ull;
+            return v;
+        };
+        std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            uint64_t code = 0;
+            for (int k = 0; k < 3; ++k) {
+                const float v = pos[static_cast<size_t>(k) * n + i];
+                const double t = std::isfinite(v) ? (static_cast<double>(v) - lo[k]) / (static_cast<double>(hi[k]) - lo[k]) : 0.0;
+                code |= spread(static_cast<uint64_t>(std::min(2097151.0, std::max(0.0, t * 2097152.0)))) << k;
+            }
+            keyed[i] = {code, static_cast<uint32_t>(i)};
+        }
+        std::sort(keyed.begin(), keyed.end());
+        std::vector<uint32_t> order(n);
+        for (uint64_t i = 0; i < n; ++i) order[i] = keyed[i].second;
+        perm.alloc(n);
+        HIP_CHECK(hipMemcpy(perm.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        spatial_blob.alloc(gs::blob_floats(n));
+        gs::launch_permute_blob(blob, perm.p, spatial_blob.p, static_cast<uint32_t>(n), static_cast<uint32_t>(st), nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(nullptr));
     }
 };
 
@@ -143,7 +203,7 @@ void quantize_sh(gs_scene* s) {  // gs_scene_quantize_sh; also run on the receiv
     if (s->sh_half) return;
     HIP_CHECK(hipSetDevice(s->device));
     s->sh16.alloc(48 * static_cast<size_t>(s->n));
-    gs::launch_sh_to_half(s->blob, s->sh16.p, static_cast<uint32_t>(s->n), static_cast<uint32_t>(gs::blob_stride(s->n)), nullptr);
+    gs::launch_sh_to_half(s->render_blob(), s->sh16.p, static_cast<uint32_t>(s->n), static_cast<uint32_t>(gs::blob_stride(s->n)), nullptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(nullptr));
     s->sh_half = true;  // read when a frame is enqueued: frames already in flight keep reading the fp32 block, which stays
@@ -471,7 +531,8 @@ struct FrameBuffers {
     DevBuf<ushort4> aabb;
     DevBuf<gs::AttrRecord> rec;  // one 64-byte record per Gaussian: what the blend gathers
     DevBuf<uint4> vis;           // the frame's visible Gaussians as dense lists (gs::AttrView::vis): level 1's input on the bin-local path
-    DevBuf<uint32_t> vis_count;  // the lists' counters, one per 128 bytes
+    DevBuf<uint32_t> vis_count;  // the lists' counters, one per 128 bytes (the word behind each: the finished frame's count)
+    bool planes_stale = false;   // the last frame on this set streamed the dense lists: tiles / depth / aabb were not written (taps rebuild them)
     uint32_t vis_region_slots = 0;
     // global depth order (only allocated when that path is taken)
     DevBuf<uint32_t> dkeys[2], dvals[2];
@@ -503,7 +564,7 @@ struct FrameBuffers {
     size_t n = 0;
     bool ready = false;
 
-    void init(size_t n_, uint32_t capacity, const std::vector<uint32_t>& mask_prep, const std::vector<uint32_t>& mask_blend) {
+    void init(size_t n_, uint32_t capacity, const std::vector<uint32_t>& mask_prep, const std::vector<uint32_t>& mask_blend, bool dense_lists) {
         n = n_;
         if (!mask_prep.empty() && !mask_blend.empty()) {
             HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, static_cast<uint32_t>(mask_prep.size()), mask_prep.data()));
@@ -517,7 +578,8 @@ struct FrameBuffers {
         depth.alloc(n);
         aabb.alloc(n);
         rec.alloc(n);
-        vis_region_slots = gs::vis_region_slots(static_cast<uint32_t>(n));  // (the lists themselves: ensure_dense_lists, on first use)
+        vis_region_slots = gs::vis_region_slots(static_cast<uint32_t>(n));
+        if (dense_lists) ensure_dense_lists();  // only scenes of >= dense_min Gaussians ever use them (16 B x N)
         l1_hist.alloc(1025 * static_cast<size_t>(gs::bin_level1_columns(static_cast<uint32_t>(n))));  // + the row of visible counts
         bin_count.alloc(1024);
         counters.alloc(1);
@@ -678,7 +740,7 @@ struct gs_renderer {
         if (const char* e = std::getenv("GS_INITIAL_CAPACITY")) want = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
         capacity = static_cast<uint32_t>(std::min<uint64_t>(want, kMaxInstances));
         parse_cu_masks();
-        sets[0].init(scene->n, capacity, mask_prep, mask_blend);
+        sets[0].init(scene->n, capacity, mask_prep, mask_blend, scene->n >= dense_min);
     }
 
     // Experiment: GS_CU_MASK_PREP / GS_CU_MASK_BLEND = hex strings, most significant CU first,
@@ -700,7 +762,7 @@ struct gs_renderer {
 
     void set_num_sets(int k) {
         for (int i = 0; i < k; ++i)
-            if (!sets[i].ready) sets[i].init(scene->n, capacity, mask_prep, mask_blend);
+            if (!sets[i].ready) sets[i].init(scene->n, capacity, mask_prep, mask_blend, scene->n >= dense_min);
         num_sets = k;
     }
 
@@ -797,19 +859,17 @@ struct gs_renderer {
         num_tiles = nt;
         ensure_tile_order(tx, ty);
 
-        gs::SceneView sv{scene->blob, scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n)),
-                          scene->sh_half ? scene->sh16.p : nullptr, scene->acut.p};
+        gs::SceneView sv{scene->render_blob(), scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n)),
+                          scene->sh_half ? scene->sh16.p : nullptr, scene->acut.p, scene->perm.p};
         gs::Counters* cnt = fb.counters.p;
         // the level-1 kernels that take their items in any order (bin-local path, bins of <= 8 x 8 tiles) stream the dense
         // list of visible Gaussians, which k_preprocess then writes beside the planes
         const bool l1_any_order = bin_local && geo.bin_shift <= 3;
-        const bool dense_list = GS_L1_DENSE && l1_any_order && n != 0 && n >= dense_min && u.width != 0 && u.height != 0;  // (the blend zeroes the lists' counters)
-        if (dense_list && !fb.vis.p) {
-            drain();
-            fb.ensure_dense_lists();
-        }
+        // (the lists exist only for scenes of >= dense_min Gaussians: FrameBuffers::init; the blend zeroes their counters)
+        const bool dense_list = GS_L1_DENSE && l1_any_order && n != 0 && n >= dense_min && fb.vis.p && u.width != 0 && u.height != 0;
         gs::AttrView av{fb.tiles.p, fb.depth.p, fb.aabb.p, fb.rec.p, dense_list ? fb.vis.p : nullptr, dense_list ? fb.vis_count.p : nullptr,
                         fb.vis_region_slots};
+        fb.planes_stale = dense_list;
 
         // the first and the last kernel of the frame clear / publish the counters themselves; the blit nodes (and
         // their fences) are only needed when one of the two is not launched
@@ -1264,8 +1324,13 @@ int gs_scene_download_cov3d(const gs_scene* s, float* cov3d) {
         const uint64_t n = s->n;
         std::vector<float> planes(6 * static_cast<size_t>(n));
         if (n) HIP_CHECK(hipMemcpy(planes.data(), s->cov3d.p, planes.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> order;  // cov3D lives in the order the frame kernels read the scene in: back to the scene's own
+        if (s->perm.p) {
+            order.resize(n);
+            HIP_CHECK(hipMemcpy(order.data(), s->perm.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
         for (uint64_t i = 0; i < n; ++i)
-            for (int k = 0; k < 6; ++k) cov3d[i * 6 + k] = planes[k * n + i];
+            for (int k = 0; k < 6; ++k) cov3d[(order.empty() ? i : order[i]) * 6 + k] = planes[k * n + i];
     });
 }
 
@@ -1276,11 +1341,11 @@ int gs_renderer_create(gs_scene* scene, gs_renderer** out) {
         if (!scene || !out) throw Error(GS_ERR_INVALID, "null argument");
         auto r = std::make_unique<gs_renderer>();
         r->scene = scene;
+        if (const char* e = std::getenv("GS_L1_DENSE_MIN")) r->dense_min = std::strtoull(e, nullptr, 10);  // (before init: sizes the buffer sets)
         r->init();
         if (const char* e = std::getenv("GS_GRAPH")) r->graph_mode = std::atoi(e) != 0;  // initial gs_set_graph_mode
         if (const char* e = std::getenv("GS_EXP_MODE")) r->exp_mode = std::min(3, std::max(0, std::atoi(e)));  // initial gs_set_exp_mode
         if (const char* e = std::getenv("GS_BLEND_CONTRACTION")) r->contract = std::atoi(e) != 0;  // initial gs_set_blend_contraction
-        if (const char* e = std::getenv("GS_L1_DENSE_MIN")) r->dense_min = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("GS_BIN_SHIFT")) r->min_bin_shift = std::min(5, std::max(2, std::atoi(e)));  // default bin edge
         if (const char* e = std::getenv("GS_SORT_PATH")) {  // initial gs_set_sort_path, for hosts that cannot call it (the viewer)
             const int mode = std::atoi(e);
@@ -1465,6 +1530,15 @@ int gs_debug_download(gs_renderer* r, int stage, void* dst, uint64_t bytes) {
         const uint64_t d = std::min<uint64_t>(r->last.num_instances, r->capacity);
         const void* src = nullptr;
         uint64_t size = 0;
+        if (r->last_set->planes_stale && (stage == GS_STAGE_TILES || stage == GS_STAGE_DEPTH || stage == GS_STAGE_AABB)) {
+            // the frame streamed the dense lists of visible Gaussians and wrote no per-Gaussian planes: rebuild them from the lists
+            FrameBuffers& fb = *r->last_set;
+            gs::launch_vis_to_planes(gs::AttrView{fb.tiles.p, fb.depth.p, fb.aabb.p, fb.rec.p, fb.vis.p, fb.vis_count.p, fb.vis_region_slots},
+                                     static_cast<uint32_t>(n), fb.stream);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(fb.stream));
+            fb.planes_stale = false;
+        }
         switch (stage) {
             case GS_STAGE_TILES: src = r->last_set->tiles.p; size = n * 4; break;
             case GS_STAGE_DEPTH: src = r->last_set->depth.p; size = n * 4; break;

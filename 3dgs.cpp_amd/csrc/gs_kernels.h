@@ -27,6 +27,10 @@ struct SceneView {
     uint32_t stride;     // blob_stride(n)
     const uint16_t* sh16;  // nullable: the SH block as binary16, n x 48 (gs_scene_quantize_sh); read instead of the fp32 one
     const float* acut;   // n floats: the alpha cut of every Gaussian (launch_alpha_cut), a function of its opacity, computed at load
+    // Nullable.  The arrays above may hold the Gaussians in ANOTHER ORDER than the scene's (gs_scene: spatial / Morton order, so
+    // that a wave's 64 Gaussians are neighbours in space: culled together, fetched together, binned together): Gaussian j of them
+    // is Gaussian perm[j] of the scene, and everything a frame writes (tiles, depth, boxes, records, list entries) goes by THAT id.
+    const uint32_t* perm;
 };
 
 // Per-frame buffers indexed by Gaussian id.
@@ -44,9 +48,9 @@ struct AttrRecord {
 static_assert(sizeof(AttrRecord) == 64, "one line per Gaussian");
 
 struct AttrView {
-    uint32_t* tiles;     // tiles_overlap (0 = culled)
-    float* depth;
-    ushort4* aabb;
+    uint32_t* tiles;     // tiles_overlap (0 = culled)      } written by k_preprocess only when `vis` is null (the plane-input
+    float* depth;        //                                 } level 1, the global path, bins of >= 16 x 16 tiles read them);
+    ushort4* aabb;       //                                 } with the dense lists: rebuilt on demand for the stage taps
     AttrRecord* rec;     // written for visible Gaussians only
     // Optional (null: not written): the frame's visible Gaussians as DENSE lists in any order, 16 bytes each --
     // {id, depth bits, tile box x0 | y0 << 16, x1 | y1 << 16} -- which the level-1 kernels of the bin-local path stream
@@ -98,6 +102,8 @@ void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, 
 // -inf: all), exact for libm's expf: the blend compares `power` with it instead of alpha with 1/255 (gs_device.h: alpha_cut)
 // *beyond_unit (device memory, nullable, zeroed by the caller): set to 1 if any opacity exceeds 1
 void launch_alpha_cut(const float* blob, float* cut, uint32_t n, uint32_t stride, uint32_t* beyond_unit, hipStream_t s);
+// dst = the blob with its Gaussians in the order perm (dst Gaussian j = src Gaussian perm[j]): 11 planes + the SH block
+void launch_permute_blob(const float* src, const uint32_t* perm, float* dst, uint32_t n, uint32_t stride, hipStream_t s);
 // *out (device) = sum of the blob's 32-bit patterns, as 64-bit integers (wrapping): what gs_dist_verify compares across ranks
 void launch_blob_checksum(const float* blob, uint64_t floats, uint64_t* out, hipStream_t s);
 // fp32 SH block of the blob -> binary16 (round to nearest even), n x 48 values
@@ -156,6 +162,9 @@ struct BinLaunch {
     int bin_shift;              // log2 S
     int grid_shift;             // 4 or 5: padded bin id = by << grid_shift | bx
 };
+// tiles / depth / aabb of the visible Gaussians rebuilt from the dense lists of the frame that just ran (stage taps: k_preprocess
+// writes no planes when level 1 streams the lists); av.vis must be the lists of that frame
+void launch_vis_to_planes(const AttrView& av, uint32_t n, hipStream_t s);
 uint32_t bin_level1_blocks(uint32_t n_items);
 uint32_t bin_level1_columns(uint32_t n_items);  // columns of the hist table: level-1 blocks over the planes or over the dense lists, whichever is more
 void bin_debug_occupancy();

@@ -31,7 +31,7 @@ struct PreUniforms {
 // Wave-private LDS of k_preprocess: the attribute records of a wave's 64 Gaussians on their way to HBM, three planes of
 // 64 float4 with a plane stride of 68 (272 dwords = 16 mod 64: the cooperative reads of 16 consecutive lanes cover all
 // 64 banks once).
-constexpr int kPrePlane = 68, kPreStage = 3 * kPrePlane;
+constexpr int kPrePlane = 68, kPreStage = 3 * kPrePlane + 16;  // + 64 scene ids (spatial order: where the records go)
 #if GS_PRE_SH_LDS
 // ... and, ahead of that (the two uses alias: the SH blocks are consumed before the records are staged), the SH blocks of up
 // to 32 of the wave's visible Gaussians, fetched by LDS-DMA: 32 x 192 B = 384 float4 (+ 64 source-lane bytes)
@@ -118,6 +118,8 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
     const size_t N = sv.stride, NC = sv.n;
     const float* __restrict__ blob = sv.blob;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
+    // i: the Gaussian's place in the arrays this kernel READS; oid: its id in the scene, under which everything is WRITTEN
+    const uint32_t oid = sv.perm ? (valid ? sv.perm[i] : 0u) : i;
 
     const int tile_w = (int)((u.width + kTile - 1) / kTile);
     const int tile_h = (int)((u.height + kTile - 1) / kTile);
@@ -290,8 +292,10 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
             } else {
                 sh_to_rgb<true>(ShFromLds{reinterpret_cast<const float*>(blk)}, x, y, z, rgb);
             }
-            av.depth[i] = depth;
-            av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1, (unsigned short)by1);
+            if (!av.vis) {  // (with the dense lists the entry below carries depth and box: the N-wide planes are not written at all)
+                av.depth[oid] = depth;
+                av.aabb[oid] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1, (unsigned short)by1);
+            }
         }
         // every lane of this round has consumed its block (the values above depend on the reads): the next round's DMA, or
         // the record stage, may overwrite the slab
@@ -333,11 +337,16 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
         float dz = pz - u.camera_position[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
         sh_to_rgb<false>(sh, dx / len, dy / len, dz / len, rgb);
-        av.depth[i] = depth;
-        av.aabb[i] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1, (unsigned short)by1);
+        if (!av.vis) {
+            av.depth[oid] = depth;
+            av.aabb[oid] = make_ushort4((unsigned short)bx0, (unsigned short)by0, (unsigned short)bx1, (unsigned short)by1);
+        }
     }
 #endif
-    if (valid) av.tiles[i] = num_tiles;  // :128 / :176
+    // :128 / :176.  With the dense lists of visible Gaussians (av.vis) nothing downstream reads the N-wide planes tiles / depth /
+    // aabb -- level 1 streams the lists, level 2 the candidate records -- so they are not written: a culled Gaussian writes
+    // nothing at all (the stage taps rebuild the planes from the lists: launch_vis_to_planes)
+    if (valid && !av.vis) av.tiles[oid] = num_tiles;
 
     // ---- the 64-byte-strided record of every visible Gaussian.  Wave-cooperative: the records pass through LDS and four
     // lanes write one record -- ONE 64-byte request per visible Gaussian (the last quarter as zeros) instead of three
@@ -347,13 +356,15 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
         const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)vis_base);
         if (vis)
             av.vis[base + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] =
-                make_uint4(i, __float_as_uint(depth), (uint32_t)bx0 | ((uint32_t)by0 << 16), (uint32_t)bx1 | ((uint32_t)by1 << 16));
+                make_uint4(oid, __float_as_uint(depth), (uint32_t)bx0 | ((uint32_t)by0 << 16), (uint32_t)bx1 | ((uint32_t)by1 << 16));
     }
     if (vis) {
         stage[0 * kPrePlane + lane] = make_float4(c00, c01, c11, opacity);
         stage[1 * kPrePlane + lane] = make_float4(uvx, uvy, rgb[0], rgb[1]);
         stage[2 * kPrePlane + lane] = make_float4(rgb[2], depth, radii, acut);
     }
+    uint32_t* const s_oid = reinterpret_cast<uint32_t*>(stage + 3 * kPrePlane);  // [64] (behind the three planes; spatial order only)
+    if (sv.perm) s_oid[lane] = oid;
     __builtin_amdgcn_wave_barrier();
     {
         float4* const rec0 = reinterpret_cast<float4*>(av.rec + (i - lane));  // the wave's first record (never dereferenced past n)
@@ -363,7 +374,8 @@ __device__ __forceinline__ void preprocess_one(const SceneView& sv, const gs_uni
             const uint32_t r = (uint32_t)t * 16u + (lane >> 2);
             if ((vm >> r) & 1ull) {  // the whole line: leaving the unused quarter out (three lanes per record) measured 2 us slower
                 const float4 val = c < 3u ? stage[c * kPrePlane + r] : make_float4(0, 0, 0, 0);
-                rec0[(size_t)r * 4 + c] = val;
+                float4* const dst = sv.perm ? reinterpret_cast<float4*>(av.rec + s_oid[r]) + c : rec0 + (size_t)r * 4 + c;
+                *dst = val;
             }
         }
     }

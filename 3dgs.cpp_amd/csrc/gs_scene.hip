@@ -75,6 +75,26 @@ void launch_alpha_cut(const float* blob, float* cut, uint32_t n, uint32_t stride
     hipLaunchKernelGGL(k_alpha_cut, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, blob + (size_t)P_OPACITY * stride, cut, n, beyond_unit);
 }
 
+// The scene's second copy in spatial order (gs_scene::make_spatial_copy): one thread per (Gaussian, 16-byte chunk of its 59 floats).
+__global__ __launch_bounds__(BLOCK) void k_permute_blob(const float* __restrict__ src, const uint32_t* __restrict__ perm,
+                                                        float* __restrict__ dst, uint32_t n, uint32_t stride) {
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t j = (uint32_t)(t / 15u), c = (uint32_t)(t % 15u);  // chunks 0..11: the SH block; 12..14: the 11 planes, four at a time
+    if (j >= n) return;
+    const uint32_t g = perm[j];
+    if (c < 12u) {
+        reinterpret_cast<float4*>(dst + (size_t)P_SH * stride)[(size_t)j * 12 + c] =
+            reinterpret_cast<const float4*>(src + (size_t)P_SH * stride)[(size_t)g * 12 + c];
+    } else {
+        for (uint32_t p = (c - 12u) * 4u; p < min((c - 11u) * 4u, (uint32_t)P_SH); ++p) dst[(size_t)p * stride + j] = src[(size_t)p * stride + g];
+    }
+}
+void launch_permute_blob(const float* src, const uint32_t* perm, float* dst, uint32_t n, uint32_t stride, hipStream_t s) {
+    if (n == 0) return;
+    const uint64_t threads = 15ull * n;
+    hipLaunchKernelGGL(k_permute_blob, dim3((uint32_t)((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, src, perm, dst, n, stride);
+}
+
 // Checksum of a scene replica (gs_dist_verify): the sum of the blob's bit patterns.
 __global__ __launch_bounds__(BLOCK) void k_blob_checksum(const uint32_t* __restrict__ words, uint64_t count, unsigned long long* __restrict__ out) {
     unsigned long long sum = 0;

@@ -101,6 +101,49 @@ def test_rotated_translated_camera(pkg, oracle, gpu):
 
 
 @pytest.mark.parametrize("dense_min", ["0", "1000000000"])
+def test_scene_read_in_spatial_order_changes_nothing(pkg, oracle, gpu, monkeypatch, dense_min):
+    """Scenes of >= GS_SPATIAL_MIN Gaussians (default 4 M) are read by the per-frame kernels from a second copy in Morton order
+    (a wave's 64 Gaussians neighbours in space); ids, taps, downloads and the broadcast blob keep the scene's own order.  Forced
+    here on small scenes, with the dense lists on and off: every stage tap, the image, the equal-depth tie order, the vertex and
+    cov3D downloads and the blob are what they are without it -- and what the oracle says."""
+    monkeypatch.setenv("GS_L1_DENSE_MIN", dense_min)
+    rec = pkg.synth.synth_records(60000, seed=23, kind="T")
+    rec[100:140, 2] = rec[100, 2]          # a run of equal depths in front of the default camera: ties go by the scene's ids
+    rec[100:140, 0:2] = rec[100, 0:2] + np.linspace(0, 0.02, 40)[:, None].astype(np.float32)
+    w, h = 800, 450
+    monkeypatch.setenv("GS_SPATIAL_MIN", "1000000000")
+    plain = pkg.Scene.from_records(rec, device=0)
+    monkeypatch.setenv("GS_SPATIAL_MIN", "0")
+    scene, rend, u, ref, img, _ = _run(pkg, oracle, rec, w, h)
+    compare_stages(pkg, rend, u, ref)
+    np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+    np.testing.assert_array_equal(rend.stage("alpha_cut")[ref["tiles"] != 0].view(np.uint32),
+                                  oracle.alpha_cut(oracle.activate_records(rec)["scale_opacity"][:, 3])[ref["tiles"] != 0].view(np.uint32))
+    np.testing.assert_array_equal(scene.download_vertices().view(np.uint32), plain.download_vertices().view(np.uint32))
+    np.testing.assert_array_equal(scene.download_cov3d().view(np.uint32), plain.download_cov3d().view(np.uint32))
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    blobs = []
+    for s_ in (scene, plain):
+        ptr, floats = s_.blob()
+        host = np.empty(floats, np.float32)
+        assert hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(floats * 4), ctypes.c_int(2)) == 0
+        blobs.append(host)
+    np.testing.assert_array_equal(blobs[0].view(np.uint32), blobs[1].view(np.uint32))  # what a broadcast replicates: the scene's order
+    rend.set_frames_in_flight(3)
+    for _ in range(5):
+        again, _ = rend.render_host(u)
+    np.testing.assert_array_equal(again.view(np.uint32), ref["image"].view(np.uint32))
+    scene.quantize_sh()  # the binary16 SH block follows the order the kernels read in
+    q, _ = rend.render_host(u)
+    plain.quantize_sh()
+    r2 = pkg.Renderer(plain)
+    r2.set_exp_mode(2)
+    q2, _ = r2.render_host(u)
+    np.testing.assert_array_equal(q.view(np.uint32), q2.view(np.uint32))
+
+
+@pytest.mark.parametrize("dense_min", ["0", "1000000000"])
 def test_level1_over_the_dense_lists_and_over_the_planes(pkg, oracle, gpu, monkeypatch, dense_min):
     """Level 1 of the bin-local path takes its items from the dense lists of visible Gaussians k_preprocess appends to
     (scenes of >= GS_L1_DENSE_MIN Gaussians; default 4 M, so the small scenes of this file would never use them) or from the
