@@ -427,7 +427,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     constexpr int kSlotBits = SLABS ? 16 : 14;  // a candidate's slot in the bin's record run: < MAXC <= 16384, or < 65536
     constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1u;
     constexpr uint32_t kMaxInBin = SLABS ? 65535u : (uint32_t)MAXC;
-    constexpr int kMaxSlabs = 12;
+    constexpr int kMaxSlabs = 16;
     __shared__ uint32_t g_cur[SLABS ? 64 : 1], t_tot[SLABS ? 64 : 1];  // a slab's list cursors; per-tile totals of the bin
     __shared__ uint32_t slab_first[SLABS ? kMaxSlabs + 1 : 1];         // first bucket of each slab
     __shared__ uint32_t cnt2[MODE == 1 ? kMaxSlabs : 1][64];           // instances per slab and tile
@@ -1175,8 +1175,11 @@ template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<8>(BuildArgs a
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<12>(BuildArgs a) { bin_fast_body<12>(a); }
 template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<16>(BuildArgs a) { bin_fast_body<16>(a); }
 // bins of up to 65535 candidates, taken in depth slabs of <= 12288 (depth-order level 4): plan, then one workgroup per slab
-__global__ __launch_bounds__(1024, 4) void k_bin_slabs(BuildArgs a) { bin_fast_body<12, 1>(a); }
-__global__ __launch_bounds__(1024, 4) void k_slab_work(BuildArgs a) { bin_fast_body<12, 2>(a); }
+#ifndef GS_SLAB_ROUNDS
+#define GS_SLAB_ROUNDS 12  // candidates per thread of the slab kernels: slabs (and the bins k_bin_slabs takes itself) of <= 1024 x this
+#endif
+__global__ __launch_bounds__(1024, 4) void k_bin_slabs(BuildArgs a) { bin_fast_body<GS_SLAB_ROUNDS, 1>(a); }
+__global__ __launch_bounds__(1024, 4) void k_slab_work(BuildArgs a) { bin_fast_body<GS_SLAB_ROUNDS, 2>(a); }
 
 template <int R2, int THREADS, bool SORT>
 static hipError_t build_prepare() {  // > 64 KiB of dynamic LDS needs the attribute
@@ -1213,10 +1216,10 @@ hipError_t bin_prepare_device() {  // once per device (gs_renderer::init)
     if (e == hipSuccess) e = fast_prepare<16>();
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_slabs), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(FastLayout<12>::WORDS * sizeof(uint32_t)));
+                                (int)(FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t)));
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_work), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(FastLayout<12>::WORDS * sizeof(uint32_t)));
+                                (int)(FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t)));
     return e;
 }
 
@@ -1249,8 +1252,8 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
         else if (level == 2) hipLaunchKernelGGL(k_bin_fast<12>, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
         else if (level == 3) hipLaunchKernelGGL(k_bin_fast<16>, dim3(bins), dim3(1024), FastLayout<16>::WORDS * sizeof(uint32_t), s, a);
         else {
-            hipLaunchKernelGGL(k_bin_slabs, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
-            hipLaunchKernelGGL(k_slab_work, dim3(kSlabWorkGroups), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
+            hipLaunchKernelGGL(k_bin_slabs, dim3(bins), dim3(1024), FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t), s, a);
+            hipLaunchKernelGGL(k_slab_work, dim3(kSlabWorkGroups), dim3(1024), FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t), s, a);
         }
     } else if (b.bin_shift <= 3) {
         launch_build<1>(a, sort, bins, s);
