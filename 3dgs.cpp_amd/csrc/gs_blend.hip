@@ -138,14 +138,13 @@ static_assert(kGuardHi < 1.0043e-4f && kGuardLo > 9.966e-5f, "the coarse window 
 
 // render.comp:83 for ONE pixel (fxa, fya) at the entry in position `pos` of the wave's list of kept entries, as the reference
 // evaluates it: is T (1 - alpha) < 1e-4 there?  Premise (the guard's induction): no earlier entry made this pixel break.
-// klist: the tile-list indices of the entries the quadrant's exact culling kept, in list order (what it dropped is skipped by
+// klist: the Gaussian ids of the entries the quadrant's exact culling kept, in list order (what it dropped is skipped by
 // every pixel of the quadrant, so the pixel's chain runs over these alone).  Every lane takes one entry per step -- two or
 // three steps for an ordinary quadrant; the arithmetic is the pair loop's with EXP = 2 (the pre-scaled conic, the alpha cut,
 // libm's expf); the T chain runs over the kept entries in list order through v_readlane.  All 64 lanes are active, every
 // value that matters is wave-uniform, and no load is in flight when this returns (the caller's pair loop keeps the next
 // chunk's prefetch outstanding: a possibly-pending load on its back-edge would make the compiler wait at every pair).
-__device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist, const uint32_t pos,
-                                              const uint32_t* __restrict__ sorted_gid, const AttrRecord* __restrict__ rec,
+__device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist, const uint32_t pos, const AttrRecord* __restrict__ rec,
                                               const uint2* __restrict__ exptab, const int lane, const float fxa, const float fya) {
 #ifdef GS_GUARD_STUB  // experiment: the replay compiled out (wrong decisions; timing only)
     return false;
@@ -158,7 +157,7 @@ __device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist
         float2 uv = make_float2(0, 0);
         float cut = __uint_as_float(0x7F800000u);
         if (p <= pos) {
-            const AttrRecord* r = rec + sorted_gid[klist[p]];
+            const AttrRecord* r = rec + klist[p];
             co = r->conic_op;
             uv = make_float2(r->uv_rg.x, r->uv_rg.y);
             cut = r->b_depth_r.w;
@@ -206,18 +205,23 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
     nxt.co = make_float4(0, 0, 0, 0);
     nxt.uv = make_float4(0, 0, 0, 0);
     nxt.bc = make_float2(0, 0);
-    uint32_t g_next = 0;
+    uint32_t g_next = 0, g_nxt = 0;  // ids of chunk +2 (in flight); GUARD: the ids `nxt` was fetched through
     {
         const uint32_t i0 = range.x + lane;
-        if (i0 < range.y) blend_fetch(nxt, sorted_gid[i0], rec);
+        if (i0 < range.y) {
+            g_nxt = sorted_gid[i0];
+            blend_fetch(nxt, g_nxt, rec);
+        }
         const uint32_t i1 = i0 + WAVE;
         if (i1 < range.y) g_next = sorted_gid[i1];
     }
     for (uint32_t base = range.x; base < range.y; base += WAVE) {
         const BlendEntry cur = nxt;
+        const uint32_t g_cur = g_nxt;  // GUARD: this chunk's Gaussian ids (for the wave's list of kept entries)
         const bool have = base + lane < range.y;
         {   // prefetch: records of chunk +1 (ids already here), ids of chunk +2
             const uint32_t i1 = base + WAVE + lane;
+            if (GUARD) g_nxt = g_next;
             if (i1 < range.y) blend_fetch(nxt, g_next, rec);
             const uint32_t i2 = i1 + WAVE;
             if (i2 < range.y) g_next = sorted_gid[i2];
@@ -252,9 +256,9 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                 abandon = true;
                 break;
             }
-            // the wave's list of kept entries, for resolve_break: tile-list index of the chunk's r-th kept entry at kbase + r
+            // the wave's list of kept entries, for resolve_break: the Gaussian id of the chunk's r-th kept entry at kbase + r
             const uint32_t at = kbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-            if (keep && at < kGuardList) klist[at] = base + (uint32_t)lane;
+            if (keep && at < kGuardList) klist[at] = g_cur;
             __builtin_amdgcn_wave_barrier();
         }
         // conic pre-scaled once per entry: (-c00/2, -c01, -c11/2).  Scaling by a power of two commutes with every
@@ -341,7 +345,7 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                                     // past the list's end, or one pixel too many: the quadrant is abandoned at the next chunk and
                                     // re-rendered exactly (necessary / cheaper)
                                     if (pos >= kGuardList || resolved >= kGuardMaxResolves) abandon = true;
-                                    else if (resolve_break(klist, pos, sorted_gid, rec, exptab, lane, fxa, fya)) mk |= 1ull << a;
+                                    else if (resolve_break(klist, pos, rec, exptab, lane, fxa, fya)) mk |= 1ull << a;
                                     ++resolved;
                                 } while (amb != 0);
                             }

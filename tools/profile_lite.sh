@@ -3,10 +3,10 @@
 # (SQ_*, FETCH_SIZE, WRITE_SIZE: three separate passes; counters never share a run with a trace domain other than the
 # kernel trace) for each of the benched workloads.  The profiled process is tools/tune_sweep.py -- the same C-ABI calls as
 # bench.py's timed region, without the torch import.
-#   gpurun --timeout 600 -- 'bash tools/profile_lite.sh r03 B C T E'   then here:   python tools/profile_summary.py r03
+#   gpurun --timeout 900 -- 'bash tools/profile_lite.sh r04 B C T E'   then here:   python tools/profile_summary.py r04
 set -u
 exec < /dev/null
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift
 WL=${@:-B}
 R=$(pwd)
@@ -31,9 +31,12 @@ for W in $WL; do
   timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc" -o p -- $D --fif 1 --frames 3 --warm 2 > /dev/null 2>&1
   timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -o f -- $D --fif 1 --frames 3 --warm 2 > /dev/null 2>&1
   timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write" -o w -- $D --fif 1 --frames 3 --warm 2 > /dev/null 2>&1
-  if [ "$W" = "B" ]; then  # the opt-in fast blend's counters as well (the A/B the default is priced against)
-    mkdir -p "$O"/pmc_fast
+  if [ "$W" = "B" ]; then  # the other blend modes' counters as well: exact (exp mode 2), unguarded v_exp_f32, and the opt-in fast blend
+    mkdir -p "$O"/pmc_exact "$O"/pmc_hw "$O"/pmc_fast "$O"/serial_exact
+    timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc_exact" -o p -- $D --fif 1 --frames 3 --warm 2 --exp-mode 2 > /dev/null 2>&1
+    timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc_hw" -o p -- $D --fif 1 --frames 3 --warm 2 --exp-mode 1 > /dev/null 2>&1
     timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc_fast" -o p -- $D --fif 1 --frames 3 --warm 2 --exp-mode 0 --contract 1 > /dev/null 2>&1
+    timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/serial_exact" -o s -- $D --fif 1 --frames $FR --exp-mode 2 --json-out "$O/serial_exact/bench.json" > /dev/null 2>&1
   fi
 done
 # per-dispatch traces are large; the stats and counter CSVs are what is summarised

@@ -11,7 +11,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 NAMES = {"B": "config B (S(1e6), 1920x1080)", "C": "config C stand-in (S(6e6), 1920x1080)",
@@ -80,11 +80,20 @@ pmc_txt = []
 for wl in [d for d in ("B", "C", "T", "E") if os.path.isdir(os.path.join(src, d))]:
     kernel_stats(wl, "serial", f"{tag}_kernel_stats_{wl}_serial.txt",
                  f"rocprofv3 --kernel-trace --stats --output-format csv -- {CMD} --fif 1   (MI355X, {NAMES[wl]}, one frame at a "
-                 "time: clean per-kernel durations; default blend = reference-exact)")
+                 "time: clean per-kernel durations; default blend = exp mode 3, the guarded v_exp_f32)")
+    if wl == "B":
+        kernel_stats(wl, "serial_exact", f"{tag}_kernel_stats_{wl}_serial_exact.txt",
+                     f"rocprofv3 --kernel-trace --stats --output-format csv -- {CMD} --fif 1 --exp-mode 2   (MI355X, {NAMES[wl]}, one frame at a "
+                     "time, the bit-identical blend: exp mode 2)")
     kernel_stats(wl, "default", f"{tag}_kernel_stats_{wl}_3inflight.txt",
                  f"rocprofv3 --kernel-trace --stats --output-format csv -- {CMD} --fif 3   (MI355X, {NAMES[wl]}, 3 frames in "
                  "flight like the default bench command; durations include contention from the other frames in flight)")
-    pmc, fetch, write, fast = counters(wl, "pmc"), counters(wl, "fetch"), counters(wl, "write"), counters(wl, "pmc_fast")
+    pmc, fetch, write = counters(wl, "pmc"), counters(wl, "fetch"), counters(wl, "write")
+    fast = counters(wl, "pmc_fast")
+    for sub in ("pmc_exact", "pmc_hw"):  # the other blend modes (config B): SQ counters only
+        for k, v in counters(wl, sub).items():
+            if k.startswith("k_blend"):
+                fast[k] = v
     if not pmc:
         continue
     b = bench_line(os.path.join(src, wl, "serial", "bench.json"))
@@ -104,13 +113,13 @@ for wl in [d for d in ("B", "C", "T", "E") if os.path.isdir(os.path.join(src, d)
                       # coalesced plane reads of k_preprocess only -- uncalibrated for 16-byte gathers
                       "fetch_scale": 2.0 if k.startswith("k_preprocess") else 1.0,
                       "valu_wave_insts": round(med(pmc[k]["SQ_INSTS_VALU"])), "salu_wave_insts": round(med(pmc[k]["SQ_INSTS_SALU"]))}
-    for k in fast:  # the opt-in fast blend (exp 0, contraction): SQ counters only
+    for k in fast:  # the blend's other modes: SQ counters only
         if k.startswith("k_blend") and k not in kernels:
-            base = kernels.get("k_blend<2, false>", {})
+            base = kernels.get("k_blend<1, false, true>", {})
             kernels[k] = {"fetch_kb": base.get("fetch_kb", 0), "write_kb": base.get("write_kb", 0), "fetch_scale": 1.0,
                           "valu_wave_insts": round(med(fast[k]["SQ_INSTS_VALU"])), "salu_wave_insts": round(med(fast[k]["SQ_INSTS_SALU"])),
                           "note": "FETCH/WRITE taken from the default blend's run (same lists, same records)"}
-            pmc_txt.append("%-34s %10.4g %10.4g %10.4g %12.4g %12.4g   (opt-in fast blend; separate run)"
+            pmc_txt.append("%-34s %10.4g %10.4g %10.4g %12.4g %12.4g   (another blend mode; separate run)"
                            % (k, med(fast[k]["SQ_INSTS_VALU"]), med(fast[k]["SQ_INSTS_SALU"]), med(fast[k]["SQ_INSTS_LDS"]),
                               med(fast[k]["SQ_WAVE_CYCLES"]), med(fast[k]["SQ_BUSY_CYCLES"])))
     for k in kernels:
