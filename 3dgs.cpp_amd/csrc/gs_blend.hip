@@ -9,7 +9,7 @@
 namespace gs {
 
 #ifndef GS_BLEND_SALU_DIET
-#define GS_BLEND_SALU_DIET 1
+#define GS_BLEND_SALU_DIET 2  // 2: the pair loop's tail hand-written as well (round 4: blend -3..4 %: the scalar unit is a co-bottleneck)
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -379,7 +379,13 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                     }
                     T = test_T;
                 }
-#if GS_BLEND_SALU_DIET
+#if GS_BLEND_SALU_DIET == 2
+                // alive &= ~mk; if (alive == 0) bm = 0 -- the pair loop then ends at its own test of bm.  Three scalar
+                // instructions, written out: left to itself the compiler spends six on "did the last pixel just saturate" (it
+                // materialises the condition as a lane mask before branching on it), and the CU's one scalar unit is a
+                // co-bottleneck of this loop (0.64 scalar instructions per vector one)
+                asm volatile("s_andn2_b64 %0, %0, %2\n\ts_cmp_eq_u64 %0, 0\n\ts_cselect_b64 %1, 0, %1" : "+s"(alive), "+s"(bm) : "s"(mk) : "scc");
+#elif GS_BLEND_SALU_DIET
                 // alive &= ~mk, kept opaque: left to itself the compiler turns "did the last pixel just saturate" into
                 // seven scalar instructions of boolean materialisation
                 asm volatile("s_andn2_b64 %0, %0, %1" : "+s"(alive) : "s"(mk) : "scc");
