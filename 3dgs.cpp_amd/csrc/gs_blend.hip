@@ -8,6 +8,10 @@
 
 namespace gs {
 
+#ifndef GS_BLEND_ASM_ACCUMULATE
+#define GS_BLEND_ASM_ACCUMULATE 1  // the guarded mode's accumulate as one hand-written exec-masked block (A/B: 0 = the compiler's form;
+                                   // the same block for the nine-instruction accumulate of the other modes measured +-0: not kept)
+#endif
 #ifndef GS_BLEND_SALU_DIET
 #define GS_BLEND_SALU_DIET 2  // 2: the pair loop's tail hand-written as well (round 4: blend -3..4 %: the scalar unit is a co-bottleneck)
 #endif
@@ -316,7 +320,7 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                     mk = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
                     {
                         uint64_t eq;  // upper half of the bit pattern == 0x38D1: inside the slice around 1e-4
-                        asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:DWORD" : "=s"(eq) : "v"(test_T), "v"(kGuardSlice));
+                        asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:DWORD" : "=s"(eq) : "v"(test_T), "s"(kGuardSlice));  // (the constant in an SGPR: as a VGPR it was re-materialised at every pair)
                         const uint64_t sl = m2 & eq;
                         if (sl != 0) {  // (3 % of the pairs)
                             uint64_t amb = sl & __builtin_amdgcn_ballot_w64(test_T >= kGuardLo && test_T < kGuardHi);  // the coarse window
@@ -357,13 +361,33 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                 STAT_ADD(8, __popcll(m2 & ~mk));   // (pixel, entry) pairs that contribute (alpha >= 1/255, before the break)
                 // the reference's loop walks a pixel's list up to and including the entry it breaks at (render.comp:60-85)
                 STAT_ADD(7, (unsigned long long)__popcll(mk) * ((base - range.x) + (uint32_t)k + 1u));
+#if GS_BLEND_ASM_ACCUMULATE
+                if (GUARD) {
+                    // :87 c += color * alpha * T; T = T (1 - alpha) for the lanes that are kept and do not break -- under the exec
+                    // mask, as ONE block of seven instructions: written by the compiler the same region costs two more branches (a
+                    // skip for "no lane updates", which never pays here, and the jump back from the out-of-line block it places
+                    // the region in).  The guarded mode owes the reference its DECISIONS bit for bit (they hang on `power` and on
+                    // the T chain, both evaluated as written) and its pixels to rounding noise: the weight alpha * T is formed once
+                    // and each channel takes one fused multiply-add (every contribution within an ULP of the reference's, no
+                    // cancellation anywhere in this sum)
+                    const uint64_t updm = m2 & ~mk;
+                    uint64_t saved;
+                    float wgt;
+                    asm volatile("s_and_saveexec_b64 %[sv], %[um]\n\t"
+                                 "v_mul_f32 %[w], %[a], %[T]\n\t"
+                                 "v_fmac_f32 %[c0], %[r], %[w]\n\t"
+                                 "v_fmac_f32 %[c1], %[g], %[w]\n\t"
+                                 "v_fmac_f32 %[c2], %[b], %[w]\n\t"
+                                 "v_mov_b32 %[T], %[tt]\n\t"
+                                 "s_or_b64 exec, exec, %[sv]"
+                                 : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [T] "+v"(T), [w] "=&v"(wgt), [sv] "=&s"(saved)
+                                 : [um] "s"(updm), [a] "v"(alpha), [r] "v"(uv.z), [g] "v"(uv.w), [b] "v"(bp.x), [tt] "v"(test_T)
+                                 : "scc");
+                } else {
+#endif
                 const bool upd = __builtin_amdgcn_inverse_ballot_w64(m2 & ~mk);
                 if (upd) {  // the accumulate runs under the exec mask: no selects
-                    if (GUARD) {
-                        // :87 c += color * alpha * T.  The guarded mode owes the reference its DECISIONS bit for bit (they hang on
-                        // `power` and on the T chain, both evaluated as written) and its pixels to rounding noise: the weight
-                        // alpha * T is formed once and each channel takes one fused multiply-add (4 instructions for 9; every
-                        // contribution within an ULP of the reference's, no cancellation anywhere in this sum)
+                    if (GUARD) {  // (the compiler's form of the block above)
                         const float wgt = alpha * T;
                         c0 = __builtin_fmaf(uv.z, wgt, c0);
                         c1 = __builtin_fmaf(uv.w, wgt, c1);
@@ -379,6 +403,9 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                     }
                     T = test_T;
                 }
+#if GS_BLEND_ASM_ACCUMULATE
+                }
+#endif
 #if GS_BLEND_SALU_DIET == 2
                 // alive &= ~mk; if (alive == 0) bm = 0 -- the pair loop then ends at its own test of bm.  Three scalar
                 // instructions, written out: left to itself the compiler spends six on "did the last pixel just saturate" (it
