@@ -206,16 +206,19 @@ int gs_set_sort_path(gs_renderer* r, int mode);
  *
  * gs_set_exp_mode -- exp() of render.comp:77, which GLSL leaves to the implementation (3 + 2|x| ULP):
  *   3  (default) the hardware's v_exp_f32 UNDER A GUARD: render.comp:82's break `T (1 - alpha) < 1e-4` is the one decision a
- *      fast exp can still flip (T drifts by a few ULP per blended entry).  A wave in which a pixel's T (1 - alpha) comes within
- *      a proven window of 1e-4 (gs_blend.hip: kGuard*; ~1e-4 relative) re-renders its 8 x 8 quadrant with mode 2's arithmetic
- *      (about 1-3 % of the quadrants; gs_frame_stats::blend_redo counts them).  Everything else has taken exactly the
- *      reference's decisions: the frame is within ROUNDING NOISE of the reference text on any scene (<= 1e-5 asserted by
- *      the GPU tests on every configuration, measured <= 4e-6), with no threshold-flip pixels -- BASELINE.json's bar is
- *      1e-4 -- at the fast modes' speed.  Not reproducible bit for bit on a CPU (v_exp_f32 is not).
+ *      fast exp can still flip (T drifts by a few ULP per blended entry).  A pixel whose T (1 - alpha) comes within a proven
+ *      window of 1e-4 (gs_blend.hip: kGuard*; a few 1e-5 relative) gets the reference's decision COMPUTED: that one pixel's
+ *      list is replayed with mode 2's arithmetic (about one pixel in 1300 at config B; gs_frame_stats::blend_resolved counts
+ *      them).  A quadrant that would need more than eight such replays is re-rendered whole with mode 2's arithmetic
+ *      (blend_redo), and a scene that holds an opacity > 1 (outside the sigmoid's range, where the bound does not apply) is
+ *      blended in mode 2 altogether.  Everything else has taken exactly the reference's decisions: the frame is within
+ *      ROUNDING NOISE of the reference text on any scene (<= 1e-5 asserted by the GPU tests on every configuration, measured
+ *      <= 4.2e-7), with no threshold-flip pixels -- BASELINE.json's bar is 1e-4 -- at nearly the unguarded loop's speed.
+ *      Not reproducible bit for bit on a CPU (v_exp_f32 is not).
  *   2  glibc's expf algorithm restated in binary64 (x 32/ln2 = k + r, 2^(k/32) from a 32-entry table, a cubic, one rounding
  *      to binary32): bit-equal to that libm on every binary32 <= 0 (checked exhaustively on the device and on the host).
  *      The frame is BIT-IDENTICAL to render.comp compiled for a CPU (tests/test_gpu_blend_modes.py, test_gpu_full_size.py);
- *      ~15 % slower than mode 3 at config B.  Domain note: valid for opacity <= 1 and power >= -104 (no underflow branch;
+ *      ~17 % fewer frames/s than mode 3 at config B.  Domain note: valid for opacity <= 1 and power >= -104 (no underflow branch;
  *      the alpha cut keeps smaller powers away from it for every finite opacity).
  *   0  the pipeline-defined binary32 polynomial (< 2 ULP): reproducible bit for bit on a CPU (the oracle's fast reading);
  *      unguarded, so a pixel may break one entry early or late where T (1 - alpha) sits within rounding of 1e-4;
