@@ -159,7 +159,7 @@ def main():
         scene0 = None
         if rank == 0:
             scene0 = pkg.Scene.load_ply(args.ply, device=local_rank)  # GSScene::load (GSScene.cpp:26-68)
-            cnt[0] = scene0.num_vertices()
+            cnt[0] = scene0.num_vertices
         if world > 1:
             dist.broadcast(cnt, src=0)
         n = int(cnt.item())
