@@ -105,7 +105,9 @@ __device__ __forceinline__ float gs_exp_blend(float x) {
 // reference's shader text compiled for the CPU (the test suite's checker), whose exp() is libm's.  Restated from the published algorithm,
 // the table generated (2^(i/32) correctly rounded, exponent pre-subtracted), and PINNED by tests/test_expf_libm.py: equal to
 // this container's libm expf on every binary32 <= 0 (2.1e9 values).  9 binary64 operations (half rate on gfx950) + one
-// LDS read: ~23 issue slots against 10 for the polynomial.  Valid for the blend's range (x <= 0, results used for x >= -7).
+// LDS read: ~23 issue slots against 10 for the polynomial.  DOMAIN: -103.97 <= x <= 0 (glibc's general path; there is no
+// underflow branch here: gs_expf_libm_full adds it).  The blend only asks for power >= the entry's alpha cut, which is >= -5.55
+// for every opacity <= 1 and >= -104 for every finite one; a NaN or infinite opacity yields alpha = 0.99 whatever exp returns.
 static __device__ const uint64_t kExpfTab[32] = {
     0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
     0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
