@@ -170,6 +170,27 @@ def test_alpha_cut_tap_equals_the_checkers_and_libm(pkg, oracle, gpu):
     scene.close()
 
 
+def test_guarded_blend_writes_the_same_bgra8_image_as_its_float_image(pkg, oracle, gpu):
+    """The B8G8R8A8_UNORM target (render.comp:98 + Swapchain.cpp:22-28) in the default mode: the packed image equals the packing of
+    the same frame's float image, and is within one LSB of the reference's packed image (rounding noise can cross a rounding
+    boundary of the UNORM conversion, nothing more), on ragged sizes too."""
+    for seed, (w, h) in enumerate([(256, 256), (333, 217), (1, 1), (17, 640)]):
+        rec = pkg.synth.synth_records(8000, seed=40 + seed, kind="A")
+        scene = pkg.Scene.from_records(rec, device=0)
+        rend = pkg.Renderer(scene)
+        rend.set_exp_mode(3)
+        u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+        img, bgra = rend.render_host(u, want_rgba=True, want_bgra=True)
+        np.testing.assert_array_equal(bgra, oracle.pack_bgra8(img))
+        ref = oracle.stages(oracle.activate_records(rec), oracle.camera_uniforms(oracle.default_camera(), w, h))["image"]
+        assert np.abs(bgra.astype(int) - oracle.pack_bgra8(ref).astype(int)).max() <= 1
+        only8, b8 = rend.render_host(u, want_rgba=False, want_bgra=True)
+        assert only8 is None
+        np.testing.assert_array_equal(b8, bgra)
+        rend.close()
+        scene.close()
+
+
 def test_guard_state_survives_mode_switches_and_frames_in_flight(pkg, oracle, gpu):
     """Mode 3 with three frames in flight and HIP-graph replay renders the same frame as one frame at a time; switching
     3 -> 2 -> 3 changes nothing; with the contractions on, mode 3 runs as mode 1 (documented)."""
