@@ -691,6 +691,7 @@ struct gs_renderer {
     // trips and k_preprocess pays 2 us for the lists; 2 M and 3.5 M, profiles/r03_l1_dense_threshold.txt: -2.2 % / -0.5 %
     // one frame at a time, +0.5 % with three in flight).  The GPU tests set it to 0 for small scenes.
     uint64_t dense_min = 4u << 20;
+    bool debug_levels = std::getenv("GS_DEBUG_LEVELS") != nullptr;
     bool refined = false;        // bins of half that edge: taken when a bin outgrows the largest in-LDS order
     bool have_frame = false;
     uint32_t retries = 0;        // lifetime count of re-run frames (statistics only)
@@ -847,15 +848,23 @@ struct gs_renderer {
         const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
         if (tx > 65535 || ty > 65535) throw Error(GS_ERR_INVALID, "resolution too large (tile box is 16-bit)");
         const uint64_t nt = static_cast<uint64_t>(tx) * ty;
+        auto lacks_buffers = [&](int at_level) {
+            return 2 * nt > fb.ranges.n || (at_level >= kGlobalLevel && !fb.dkeys[0].p) || (at_level == gs::kBinSlabLevel && !fb.slabs.p);
+        };
+        if (lacks_buffers(frame_level())) {
+            // (re)allocation: wait for queued frames that still use the old buffers.  Retiring them may re-run a frame at another
+            // depth-order level or bin size (retire_oldest): what THIS frame runs with is decided after the wait, not before
+            // -- a frame queued with the level of before the wait fails at once and, being judged as a failure of the new
+            // level, used to push the renderer onto the global path for slab_hold frames
+            drain();
+            const int at_level = frame_level();
+            fb.ranges.ensure(2 * nt);
+            if (at_level >= kGlobalLevel) fb.ensure_depth_order();
+            if (at_level == gs::kBinSlabLevel && !fb.slabs.p) fb.slabs.alloc(static_cast<size_t>(gs::kSlabCapacity) * gs::kSlabDescBytes);
+        }
         const BinGeometry geo = bin_geometry(tx, ty);
         const int lv = frame_level();
         const bool bin_local = lv < kGlobalLevel;
-        if (2 * nt > fb.ranges.n || (!bin_local && !fb.dkeys[0].p) || (lv == gs::kBinSlabLevel && !fb.slabs.p)) {
-            drain();  // (re)allocation: wait for queued frames that still use the old buffers
-            fb.ranges.ensure(2 * nt);
-            if (!bin_local) fb.ensure_depth_order();
-            if (lv == gs::kBinSlabLevel && !fb.slabs.p) fb.slabs.alloc(static_cast<size_t>(gs::kSlabCapacity) * gs::kSlabDescBytes);
-        }
         num_tiles = nt;
         ensure_tile_order(tx, ty);
 
@@ -1044,10 +1053,23 @@ struct gs_renderer {
                     // D instances and E1 level-1 candidates share the capacity
                     need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, q.h_counters->bin_entries));
                 }
-                if (q.level < kGlobalLevel && (q.h_counters->overflow & 2u)) bin_too_big = true;
-                fullest = std::max(fullest, q.h_counters->max_bin);
+                // (a frame that ran with another level or bin size than the renderer's current ones says nothing about those)
+                const uint32_t qtx = (q.u.width + gs::kTile - 1) / gs::kTile, qty = (q.u.height + gs::kTile - 1) / gs::kTile;
+                const bool current = q.level == frame_level() && q.bin_shift == bin_geometry(qtx, qty).bin_shift;
+                if (q.level < kGlobalLevel && (q.h_counters->overflow & 2u) && current) bin_too_big = true;
+                if (current) fullest = std::max(fullest, q.h_counters->max_bin);
             }
             const int failed_level = sl.level;
+            if (debug_levels) {  // GS_DEBUG_LEVELS: what made the renderer change its depth-order level
+                std::fprintf(stderr, "[gs3d] frame %llu overflowed at level %d (refined %d, hold %u):", (unsigned long long)(frames_enqueued - pending),
+                             failed_level, (int)refined, slab_hold);
+                for (int k = 0; k < pending; ++k) {
+                    const FrameSlot& q = slots[(frames_enqueued - pending + k) % kSlots];
+                    std::fprintf(stderr, " [lvl %d bin 2^%d ovf %u max_bin %u E1 %u D %u slabs %u]", q.level, q.bin_shift, q.h_counters->overflow,
+                                 q.h_counters->max_bin, q.h_counters->bin_entries, q.h_counters->instances, q.h_counters->slabs);
+                }
+                std::fprintf(stderr, " capacity %u\n", capacity);
+            }
             // the queued frames are dropped from the ring first: whatever is thrown below, the renderer stays usable
             frames_enqueued -= pending;
             pending = 0;

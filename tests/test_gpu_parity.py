@@ -755,6 +755,41 @@ def test_graph_replay_mode(pkg, oracle, gpu, monkeypatch):
     scene.close()
 
 
+def test_level_changes_with_frames_in_flight_stay_bin_local(pkg, gpu, monkeypatch):
+    """A fresh renderer, three frames in flight, a cluster whose fullest bin holds > 65535 candidates at 8 x 8 tiles and between
+    16384 and 65535 at 4 x 4: the first frame climbs level 0 -> smaller bins at level 3 -> depth slabs (level 4) while the next
+    frames are being queued.  A frame queued behind it must run with the level of after that climb; round 4's T(6e6) profile
+    showed one being queued with the level of before it (the wait for buffer allocation sat between the decision and the
+    launch), failing at once and sending the renderer to the global path for 32 frames."""
+    monkeypatch.setenv("GS_SORT_PATH", "0")
+    rec = pkg.synth.synth_records(360000, seed=91, kind="A")
+    rec[:, 0] = rec[:, 0] * 0.35 + 0.3      # the cluster of test_bins_are_refined_before_the_global_path, 4.5 x as dense
+    rec[:, 1] = rec[:, 1] * 0.35 - 0.2
+    rec[:, 2] = -4.0 + 0.05 * rec[:, 2]
+    rec[:, 55:58] -= 1.5
+    w, h = 1920, 1080
+    scene = pkg.Scene.from_records(rec)
+    rend = pkg.Renderer(scene)
+    rend.set_frames_in_flight(3)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    hb = _HipBuffers()
+    ptrs = [hb.alloc(w * h * 16) for _ in range(3)]
+    for i in range(9):
+        rend.render(u, ptrs[i % 3])
+    rend.synchronize()
+    st = rend.stats()
+    assert st.sort_path == 2 and st.sort_level == 4 and st.bin_tiles == 4 and 16384 < st.max_bin_entries <= 65535, \
+        (st.sort_path, st.sort_level, st.bin_tiles, st.max_bin_entries, st.retries)
+    assert st.retries >= 2, st.retries  # smaller bins, then slabs
+    imgs = [hb.download(p, (h, w, 4), np.float32) for p in ptrs]
+    host, _ = rend.render_host(u)
+    for img in imgs:
+        np.testing.assert_array_equal(img.view(np.uint32), host.view(np.uint32))
+    rend.close()
+    scene.close()
+    hb.close()
+
+
 def test_bins_are_refined_before_the_global_path(pkg, oracle, gpu, monkeypatch):
     """Automatic mode, a cluster that puts > 16384 candidates into one 8 x 8-tile bin but fits once the bins are
     4 x 4 tiles: the frame is re-run with the smaller bins and stays on the bin-local path (what keeps 6 M-Gaussian
