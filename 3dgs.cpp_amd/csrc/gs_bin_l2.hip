@@ -57,10 +57,16 @@ __device__ __forceinline__ uint32_t bin_local_box(const BinGrid& g, uint32_t bin
 constexpr int kBuildSlots = 16;  // chunks per fill round (one or four per wave)
 
 #ifdef GS_BUILD_TIMING
-// debug instrumentation (separate build, never the shipped library): per bin, the constant-rate clock at phase ends
+// debug instrumentation (separate build, never the shipped library: make variant TAG=tm DEFS=-DGS_BUILD_TIMING, read by
+// tools/build_timing.py and tools/slab_timing.py): the constant-rate clock at phase ends, one row per bin (rows 0 .. 511) or per
+// depth slab (rows 512 + descriptor % 512; k_slab_work's prologue stamps row 1023)
 __device__ unsigned long long g_build_t[1024][10];
-#define BUILD_T(i) do { if (threadIdx.x == 0) g_build_t[blockIdx.x][i] = wall_clock64(); } while (0)
+#define BUILD_ROW(v) uint32_t build_row = (v)
+#define BUILD_ROW_SET(v) build_row = (v)
+#define BUILD_T(i) do { if (threadIdx.x == 0) g_build_t[build_row][i] = wall_clock64(); } while (0)
 #else
+#define BUILD_ROW(v) do { } while (0)
+#define BUILD_ROW_SET(v) do { } while (0)
 #define BUILD_T(i) do { } while (0)
 #endif
 
@@ -80,6 +86,7 @@ struct BuildLayout {
 
 template <int R2, int THREADS, bool SORT>
 __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
+    BUILD_ROW(blockIdx.x);
     using L = BuildLayout<R2, THREADS, SORT>;
     constexpr int NW = L::NW, MAXC = L::MAXC, SS = L::SS, PER = kBuildSlots / NW;  // PER chunks per wave and round
     extern __shared__ uint32_t smem[];
@@ -370,9 +377,9 @@ extern "C" int gs_debug_build_timing(unsigned long long* out /* [1024][10] */) {
 //      (tile, depth) keys over index-ordered input gives).  Equal keys are adjacent now; every element of a run of
 //      equal keys counts the smaller ids of its run and moves there.  Runs are short (two or three) unless the scene
 //      is degenerate; a run longer than 64 sends the whole bin through id passes followed by the depth passes again;
-//   4. per candidate: its tile box inside the bin (16 bits) and, with LDS atomics, how many candidates of each
-//      64-candidate chunk cover each tile; prefix over the chunks per tile; tile totals -> a segment of the list
-//      buffer (one atomic add), the tile ranges;
+//   4. per candidate: its tile box inside the bin (16 bits); per 64-candidate chunk and tile, how many candidates of the
+//      chunk cover the tile (16 tiles: one counted ballot per tile; 64 tiles: a bit-matrix transpose); prefix over the
+//      chunks per tile; tile totals -> a segment of the list buffer (one atomic add), the tile ranges;
 //   5. fill: a wave takes a chunk; for each tile of the bin, a ballot of the lanes whose box covers it ranks them in
 //      list order, and they store their ids at  tile start + chunk prefix + rank  -- consecutive addresses.
 // ROUNDS = candidates per thread: 4, 8, 12 or 16 (4096 / 8192 / 12288 / 16384 per bin; 48 / 80 / 112 / 144 KiB of LDS).
@@ -386,6 +393,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, ui
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(addr >> 32));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
                                              __builtin_amdgcn_readfirstlane((int)bytes), 0x27000);
+}
+
+// the 4 x 4 tiles of a bin that a bin-local box (x0 | y0 << 4 | x1 << 8 | y1 << 12, inclusive) covers: bit y * 4 + x
+__device__ __forceinline__ uint32_t cover16(uint32_t pb) {
+    const uint32_t lx0 = pb & 15u, ly0 = (pb >> 4) & 15u, lx1 = (pb >> 8) & 15u, ly1 = (pb >> 12) & 15u;
+    const uint32_t xm = ((2u << lx1) - (1u << lx0)) & 15u;                   // columns lx0 .. lx1
+    const uint32_t rows = (16u << (4u * ly1)) - (1u << (4u * ly0));          // every bit of rows ly0 .. ly1
+    return (xm * 0x1111u) & rows;
 }
 
 template <int ROUNDS>
@@ -433,6 +448,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     __shared__ uint32_t cnt2[MODE == 1 ? kMaxSlabs : 1][64];           // instances per slab and tile
     __shared__ uint32_t s_fill;
 
+    BUILD_ROW(MODE == 2 ? 1023u : blockIdx.x);
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     // one workgroup per ON-SCREEN bin (the grid is bins_x * bins_y: with the padding of the bin grid in it, workgroups
     // that exit at once upset the dispatcher's placement and a few CUs end up with three of the real ones)
@@ -811,15 +827,35 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
                 bx[r] = rec.z;
             }
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (base + r * THREADS + tid < c_total) {
-                    const uint32_t bk = (k[r] - g_kmin) >> g_sh;
-                    uint32_t sl = 0;
-                    for (uint32_t j = 1; j < n_slabs; ++j) sl += bk >= slab_first[j] ? 1u : 0u;
-                    const uint32_t pb = bx[r], lx0 = pb & 15u, ly0 = (pb >> 4) & 15u, lx1 = (pb >> 8) & 15u, ly1 = (pb >> 12) & 15u;
+            for (int r = 0; r < 8; ++r) {
+                const bool valid = base + r * THREADS + tid < c_total;
+                const uint32_t bk = (k[r] - g_kmin) >> g_sh;
+                uint32_t sl = 0;
+                for (uint32_t j = 1; j < n_slabs; ++j) sl += bk >= slab_first[j] ? 1u : 0u;
+                const uint32_t pb = bx[r];
+                if (S == 4) {
+                    // 16 tiles: per tile the ballot of the covering lanes, per slab the lanes that belong to it -- lane t adds
+                    // the count of (slab, tile t) with ONE atomic per wave, slab and 64 records (an atomic per record and
+                    // tile put all 1024 threads on the same 16 n_slabs counters)
+                    const uint32_t cm = valid ? cover16(pb) : 0u;
+                    if (__builtin_amdgcn_ballot_w64(cm != 0) == 0) continue;
+                    uint64_t bal[16];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) bal[t] = __builtin_amdgcn_ballot_w64(((cm >> t) & 1u) != 0);
+                    for (uint32_t j = 0; j < n_slabs; ++j) {
+                        const uint64_t mk = __builtin_amdgcn_ballot_w64(valid && sl == j);
+                        if (mk == 0) continue;
+                        uint32_t mine = 0;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) mine = lane == t ? (uint32_t)__popcll(bal[t] & mk) : mine;
+                        if (lane < 16 && mine != 0) atomicAdd(&cnt2[j][lane], mine);
+                    }
+                } else if (valid) {
+                    const uint32_t lx0 = pb & 15u, ly0 = (pb >> 4) & 15u, lx1 = (pb >> 8) & 15u, ly1 = (pb >> 12) & 15u;
                     for (uint32_t y = ly0; y <= ly1; ++y)
                         for (uint32_t x = lx0; x <= lx1; ++x) atomicAdd(&cnt2[sl][(y << a.g.bin_shift) + x], 1u);
                 }
+            }
         }
         __syncthreads();
         if (tid < 64) {  // per tile: the bin's total; cnt2 becomes the exclusive prefix over the slabs
@@ -1038,21 +1074,25 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         for (uint32_t k = tid; k < (uint32_t)MAXC / 2; k += THREADS) smem[MAXC / 2 + k] = 0;  // the table
         if (tid < 64) t_cnt[tid] = 0;
         __syncthreads();
-        uint32_t* const tbl_words = smem + MAXC / 2;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t e = r * THREADS + tid;
-            if (e < c) {
-                const uint32_t pb = pb16[r];
-                s_box[e] = (uint16_t)pb;  // x0 | y0 << 4 | x1 << 8 | y1 << 12, inclusive upper bounds
-                if (S == 4) {  // 16 tiles: a handful of LDS atomics per candidate (16-bit counters, two to a word; <= 64 each)
-                    const uint32_t lx0 = pb & 15u, ly0 = (pb >> 4) & 15u, lx1 = (pb >> 8) & 15u, ly1 = pb >> 12;
-                    const uint32_t row = (e >> 6) * 64u;
-                    for (uint32_t y = ly0; y <= ly1; ++y)
-                        for (uint32_t x = lx0; x <= lx1; ++x) {
-                            const uint32_t idx = row + (y << 2) + x;
-                            atomicAdd(&tbl_words[idx >> 1], 1u << (16u * (idx & 1u)));
-                        }
+            const uint32_t pb = pb16[r];
+            if (e < c) s_box[e] = (uint16_t)pb;  // x0 | y0 << 4 | x1 << 8 | y1 << 12, inclusive upper bounds
+            if (S == 4) {
+                // 16 tiles: this wave holds chunk r * NW + w; the ballot of the lanes whose box covers tile t, counted, is the
+                // chunk's entry for tile t (LDS atomics on the 16 counters of a chunk -- 64 lanes, four tiles each, on eight
+                // words -- took 19 us of a 12288-candidate slab's 82: profiles/r04_slab_phases_T.txt)
+                const uint32_t ch = (uint32_t)r * NW + (uint32_t)__builtin_amdgcn_readfirstlane(w);
+                if (ch < nch) {
+                    const uint32_t cm = e < c ? cover16(pb) : 0u;
+                    uint32_t mine = 0;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const uint64_t bal = __builtin_amdgcn_ballot_w64(((cm >> t) & 1u) != 0);
+                        mine = lane == t ? (uint32_t)__popcll(bal) : mine;
+                    }
+                    s_tbl[ch][lane] = (uint16_t)mine;
                 }
             }
         }
@@ -1121,10 +1161,10 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         if (S == 4) {
             // 16 tiles: for each, the ballot of the covering lanes ranks them in list order and they store their ids at
             // consecutive addresses
+            const uint32_t cm = valid ? cover16(pb) : 0u;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int tx = t & 3, ty = t >> 2;
-                const bool covered = valid && tx >= lx0 && tx <= lx1 && ty >= ly0 && ty <= ly1;
+                const bool covered = ((cm >> t) & 1u) != 0;
                 const uint64_t bal = __builtin_amdgcn_ballot_w64(covered);
                 if (bal == 0) continue;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -1161,8 +1201,12 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
                 s_flag = 0;
             }
             __syncthreads();
+            BUILD_ROW_SET(512u + (d & 511u));
+            BUILD_T(1);
             slab_body(0u);
+            BUILD_T(7);
         }
+        BUILD_ROW_SET(1023u);
     }
     BUILD_T(7);
 }
