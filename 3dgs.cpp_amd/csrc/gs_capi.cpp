@@ -693,6 +693,7 @@ struct gs_renderer {
     uint64_t dense_min = 4u << 20;
     bool debug_levels = std::getenv("GS_DEBUG_LEVELS") != nullptr;
     bool refined = false;        // bins of half that edge: taken when a bin outgrows the largest in-LDS order
+    bool settle_level = false;   // the next clean frame at the level a refinement jumped to tells which level its bins really need
     bool have_frame = false;
     uint32_t retries = 0;        // lifetime count of re-run frames (statistics only)
     uint32_t redo_chain = 0;     // consecutive re-runs since a frame last retired cleanly: the runaway guard
@@ -1084,7 +1085,8 @@ struct gs_renderer {
                 while (wanted < kGlobalLevel && fullest > level_limit(wanted)) ++wanted;
                 if (wanted >= gs::kBinSlabLevel && can_refine(sl.u)) {  // smaller bins before slabs or the global path
                     refined = true;
-                    wanted = gs::kBinSlabLevel - 1;
+                    wanted = gs::kBinSlabLevel - 1;  // (what the smaller bins hold is not known yet: the largest in-LDS order)
+                    settle_level = true;
                 } else {
                     if (sort_mode == 2 && wanted >= kGlobalLevel)
                         throw Error(GS_ERR_OVERFLOW, slabs_unsuitable
@@ -1109,6 +1111,13 @@ struct gs_renderer {
         }
         redo_chain = 0;
         if (sl.level == gs::kBinSlabLevel && ++slab_clean_frames >= 64) slab_hold = 32;  // the slabs work on this scene (again)
+        if (settle_level && sort_mode != 1 && sl.level == level && level < kGlobalLevel) {
+            // the first clean frame after the bins were refined: its fullest bin says which order the smaller bins need -- straight
+            // there instead of 32 frames at the largest one per step down (config C: level 3 -> 2, k_bin_fast<16> -> <12>)
+            while (level > 0 && sl.h_counters->max_bin <= level_limit(level - 1) * 7 / 8) --level;
+            frames_since_fallback = 0;
+            settle_level = false;
+        }
         if (sort_mode != 1 && level > 0) {  // one level down once the bins have fitted it for a while
             if (sl.h_counters->max_bin <= level_limit(level - 1) * 7 / 8) {
                 // (from the global path back to the slabs: only after slab_hold frames, see there)

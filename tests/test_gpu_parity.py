@@ -807,3 +807,11 @@ def test_bins_are_refined_before_the_global_path(pkg, oracle, gpu, monkeypatch):
     assert st.max_bin_entries <= 16384
     compare_stages(pkg, rend, u, ref)
     np.testing.assert_array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+    # the refinement jumps to the largest in-LDS order (level 3); the first clean frame tells what the smaller bins need and the
+    # next frame runs there, not 32 frames per step later
+    limits = [4096, 8192, 12288, 16384]
+    fits = min(lv for lv in range(4) if lv == 3 or st.max_bin_entries <= limits[lv] * 7 // 8)
+    img2, _ = rend.render_host(u)
+    st2 = rend.stats()
+    assert st.sort_level == 3 and st2.sort_level == fits and st2.retries == st.retries, (st.sort_level, st2.sort_level, fits, st.max_bin_entries)
+    np.testing.assert_array_equal(img2.view(np.uint32), img.view(np.uint32))
