@@ -121,7 +121,12 @@ def _check(rc):
 
 
 def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
+    """Pointer to a numpy array's data for the duration of a call (the caller holds the array).  NOT `a.ctypes.data_as(...)`: that
+    builds a reference cycle per call (the pointer object keeps the array, the array's ctypes helper keeps the pointer), i.e. two
+    objects of cyclic garbage per gs_render -- enough to trigger Python's full (generation-2) collection once per ~2 000 frames,
+    which in a process that has imported torch walks ~170 000 objects and holds the frame loop for 35-45 ms: the "once per run"
+    stall of bench.py's rounds 2-4 (profiles/r05_stall_hunt.txt)."""
+    return C.c_void_p(a.ctypes.data)
 
 
 def device_count():

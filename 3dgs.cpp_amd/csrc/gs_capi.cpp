@@ -692,6 +692,23 @@ struct gs_renderer {
     // one frame at a time, +0.5 % with three in flight).  The GPU tests set it to 0 for small scenes.
     uint64_t dense_min = 4u << 20;
     bool debug_levels = std::getenv("GS_DEBUG_LEVELS") != nullptr;
+    // GS_DEBUG_STALLS=<ms>: a gs_render call that keeps the host longer than this is reported on stderr with the time each of
+    // its parts took (wait for a free frame slot; the launches of each pass; the closing event records) -- how the runtime's
+    // own hiccups (profiles/r05_stall_*.txt) are told from the renderer's
+    double stall_ms = std::getenv("GS_DEBUG_STALLS") ? std::atof(std::getenv("GS_DEBUG_STALLS")) : 0.0;
+    static constexpr int kLaps = 10;
+    std::chrono::steady_clock::time_point laps[kLaps];
+    void lap(int k) {
+        if (stall_ms > 0.0) laps[k] = std::chrono::steady_clock::now();
+    }
+    void report_stall() {
+        if (stall_ms <= 0.0) return;
+        auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(laps[b] - laps[a]).count(); };
+        if (ms(0, 9) < stall_ms) return;
+        std::fprintf(stderr, "[gs3d] stall: frame %llu held the host %.3f ms: wait-for-slot %.3f, setup %.3f, preprocess %.3f, order %.3f, level1 %.3f, "
+                             "level2 %.3f, blend %.3f, closing events %.3f\n", (unsigned long long)(frames_enqueued - 1), ms(0, 9), ms(0, 1), ms(1, 2), ms(2, 3),
+                     ms(3, 4), ms(4, 5), ms(5, 6), ms(6, 7), ms(7, 9));
+    }
     bool refined = false;        // bins of half that edge: taken when a bin outgrows the largest in-LDS order
     bool settle_level = false;   // the next clean frame at the level a refinement jumped to tells which level its bins really need
     bool have_frame = false;
@@ -868,6 +885,7 @@ struct gs_renderer {
         const bool bin_local = lv < kGlobalLevel;
         num_tiles = nt;
         ensure_tile_order(tx, ty);
+        lap(2);
 
         gs::SceneView sv{scene->render_blob(), scene->cov3d.p, n, static_cast<uint32_t>(gs::blob_stride(n)),
                           scene->sh_half ? scene->sh16.p : nullptr, scene->acut.p, scene->perm.p};
@@ -893,6 +911,7 @@ struct gs_renderer {
         auto passes = [&](const gs::FrameParams* fp, bool spans, hipStream_t bstream) {
             gs::launch_preprocess(sv, u, av, cnt, fp, stream);
             if (spans) HIP_CHECK(hipEventRecord(ev[1], stream));
+            lap(3);
             if (!bin_local && n != 0) {
                 // ---- global depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
                 const int blocks = std::max(1, std::min<int>(gs::kSortMaxBlocks, (n + gs::kSortTileKeys - 1) / gs::kSortTileKeys));
@@ -921,6 +940,7 @@ struct gs_renderer {
                 }
             }
             if (spans) HIP_CHECK(hipEventRecord(ev[2], stream));
+            lap(4);
             if (n != 0) {
                 gs::BinLaunch b{};
                 b.order = bin_local ? nullptr : fb.dvals[1].p;
@@ -952,6 +972,7 @@ struct gs_renderer {
                 if (spans) HIP_CHECK(hipEventRecord(ev[3], stream));
                 gs::launch_bin_level1_scatter(b, l1_any_order, stream);
                 if (spans) HIP_CHECK(hipEventRecord(ev[4], stream));
+                lap(5);
                 // ---- level 2: order inside the bin (bin-local path), tile ranges, per-tile lists ----
                 gs::launch_bin_level2(b, lv, stream);
             } else if (spans) {
@@ -959,6 +980,7 @@ struct gs_renderer {
                 HIP_CHECK(hipEventRecord(ev[4], stream));
             }
             if (spans) HIP_CHECK(hipEventRecord(ev[5], stream));
+            lap(6);
             // ---- blend ----
             if (bstream != stream) {
                 HIP_CHECK(hipEventRecord(fb.prep_done, stream));
@@ -966,6 +988,7 @@ struct gs_renderer {
             }
             gs::launch_blend(fb.ranges.p, fb.sorted.p, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
                              fused_counters ? sl.h_counters : nullptr, blend_exp_mode(), contract, fp, bstream);
+            lap(7);
         };
         depth_order = bin_local ? nullptr : fb.dvals[1].p;
         sorted_gid = fb.sorted.p;
@@ -1025,6 +1048,7 @@ struct gs_renderer {
         sl.timed = timing && !replay;
         ++frames_enqueued;
         ++pending;
+        lap(9);
     }
 
     FrameSlot& oldest() { return slots[(frames_enqueued - pending) % kSlots]; }
@@ -1409,8 +1433,13 @@ int gs_render(gs_renderer* r, const gs_uniforms* u, float* d_rgba, uint8_t* d_bg
     return guarded([&] {
         if (!r || !u) throw Error(GS_ERR_INVALID, "null argument");
         if (u->width == 0 || u->height == 0) throw Error(GS_ERR_INVALID, "empty framebuffer");
+        r->lap(0);
         r->make_room();  // at most in_flight_limit frames queued; resolves pending overflows first
+        r->lap(1);
+        if (r->stall_ms > 0.0)
+            for (int k = 2; k < gs_renderer::kLaps; ++k) r->laps[k] = r->laps[1];
         r->enqueue(*u, d_rgba, d_bgra);
+        r->report_stall();
     });
 }
 

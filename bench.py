@@ -22,6 +22,7 @@ and `cpu_baseline` (the oracle -- CPU restatement of the reference shaders -- on
 """
 import argparse
 import ctypes
+import gc
 import json
 import math
 import os
@@ -237,6 +238,12 @@ def main():
     sync_all()
     rend.timing_totals(reset=True)
     rend.frame_intervals(reset=True)
+    # The harness must not stall the frame loop it times: rounds 2-4 lost one 35-45 ms batch per run to Python's full garbage
+    # collection (cyclic garbage from numpy's `ctypes.data_as` in the binding, 170 000 objects to walk once torch is imported;
+    # profiles/r05_stall_hunt.txt).  The binding no longer produces garbage; what setup left behind is collected now and the
+    # survivors are moved out of the collector's sight, so nothing count-triggered can land inside the timed region.
+    gc.collect()
+    gc.freeze()
 
     def timed_batch():
         """EXACTLY K frames between barrier + synchronize on both sides; max over ranks."""
@@ -350,6 +357,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            # every timed frame over every timed second (value is the MEDIAN batch): what a consumer that runs for minutes gets
+            "sustained_frames_per_s": round(world * args.steps * len(batch_s) / float(np.sum(batch_s)), 2),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -19,8 +19,18 @@ oracle/glsl_cpu/glsl_compat.hpp with g++ -ffp-contract=off.  The rewrites are pu
      and silently widen the arithmetic).
   4. the text is wrapped in `namespace glsl { namespace cs_<name> { ... } }` followed by glsl_cpu/harness.hpp.
 
-The radix sort (sort/hist.comp + sort/sort.comp x 8, Renderer.cpp:598-629) is NOT run: its result is by
-construction a stable ascending sort of the 64-bit keys, which gsr_sort_pairs does with std::stable_sort.
+The radix sort (sort/hist.comp + sort/sort.comp x 8, Renderer.cpp:598-629) is compiled and RUN like the rest
+(gsr_radix_sort_pairs): its workgroups -- barrier(), `shared` arrays, subgroup operations, shared-memory atomics -- execute
+on glsl_cpu/workgroup.hpp (one fiber per invocation).  Two more syntactic rewrites apply to those two files:
+
+  5. comments are stripped first (the buffer blocks carry comments inside their braces);
+  6. `shared T[N] name;` -> `static thread_local T name[(N) + 64];` (one copy per host thread = per running workgroup; the 64
+     elements of slack because sort.comp:128 reads `sums[lsID]` for every lane of a 32-wide subgroup from an 8-element array --
+     harmless on a GPU, where only lanes < 8 reach the result, and kept harmless here);
+     `layout (local_size_x = X) in;` -> `static const uint local_size[3] = {X, 1, 1};`.
+
+The per-frame checks use gsr_sort_pairs (std::stable_sort: what eight stable LSD passes over all 64 key bits amount to);
+tests/test_oracle_vs_ref.py pins the shader text's result to it.
 
 Usage: python oracle/build_ref.py [--reference /root/reference] [--keep-generated DIR]
 """
@@ -35,6 +45,7 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(HERE, "_ref")
 SHADERS = ["precomp_cov3d", "preprocess", "prefix_sum", "preprocess_sort", "tile_boundary", "render"]
+WORKGROUP_SHADERS = {"sort_hist": "sort/hist.comp", "sort_sort": "sort/sort.comp"}  # need barrier() / shared / subgroup operations
 CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-w"]
 
 FLOAT_LIT = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![\w.])")
@@ -42,9 +53,19 @@ BUFFER_BLOCK = re.compile(r"layout\s*\([^)]*\)\s*(?:readonly\s+|writeonly\s+)?bu
 UNIFORM_BLOCK = re.compile(r"layout\s*\([^)]*\)\s*uniform\s+\w+\s*\{(.*?)\}\s*;", re.S)
 IMAGE_DECL = re.compile(r"layout\s*\([^)]*\)\s*uniform\s+(?:writeonly\s+|readonly\s+)?image2D\s+(\w+)\s*;")
 LOCAL_SIZE = re.compile(r"layout\s*\(\s*local_size_x\s*=\s*([^,]+),\s*local_size_y\s*=\s*([^,]+),\s*local_size_z\s*=\s*([^)]+)\)\s*in\s*;")
+LOCAL_SIZE_X = re.compile(r"layout\s*\(\s*local_size_x\s*=\s*([^,)]+)\)\s*in\s*;")
+SHARED_ARRAY = re.compile(r"\bshared\s+(\w+)\s*\[([^\]]+)\]\s*(\w+)\s*;")
 
 
-def glsl_to_cpp(text, shader_dir):
+def glsl_to_cpp(text, shader_dir, workgroup=False):
+    if workgroup:  # rewrites 5 and 6
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        text = SHARED_ARRAY.sub(lambda m: f"static thread_local {m.group(1)} {m.group(3)}[({m.group(2)}) + 64];", text)
+        text = LOCAL_SIZE_X.sub(lambda m: f"static const uint local_size[3] = {{{m.group(1)}, 1, 1}};", text)
+        if re.search(r"\bshared\b", text):
+            raise RuntimeError("unhandled shared declaration")
+
     def include(m):
         with open(os.path.join(shader_dir, m.group(1))) as f:
             return f.read() + "\n"
@@ -91,15 +112,18 @@ def main():
         gen_dir = args.keep_generated or tmp
         os.makedirs(gen_dir, exist_ok=True)
         objs = []
-        for name in SHADERS + ["common"]:
-            path = os.path.join(shader_dir, name + (".glsl" if name == "common" else ".comp"))
+        files = {name: name + ".comp" for name in SHADERS}
+        files.update(WORKGROUP_SHADERS)
+        for name in list(files) + ["common"]:
+            path = os.path.join(shader_dir, "common.glsl" if name == "common" else files[name])
             provenance.append(f"{os.path.relpath(path, args.reference)} sha256={sha256(path)}")
-        for name in SHADERS:
-            with open(os.path.join(shader_dir, name + ".comp")) as f:
-                body = glsl_to_cpp(f.read(), shader_dir)
+        for name in files:
+            with open(os.path.join(shader_dir, files[name])) as f:
+                body = glsl_to_cpp(f.read(), shader_dir, workgroup=name in WORKGROUP_SHADERS)
             src = os.path.join(gen_dir, f"cs_{name}.cpp")
+            header = "workgroup.hpp" if name in WORKGROUP_SHADERS else "glsl_compat.hpp"
             with open(src, "w") as f:
-                f.write(f'#include "glsl_compat.hpp"\n#define CS_{name.upper()} 1\n'
+                f.write(f'#include "{header}"\n#define CS_{name.upper()} 1\n'
                         f"namespace glsl {{ namespace cs_{name} {{\n{body}\n#include \"harness.hpp\"\n}} }}\n")
             obj = os.path.join(tmp, f"cs_{name}.o")
             subprocess.check_call(["g++", *CXXFLAGS, "-I", compat, "-c", src, "-o", obj])

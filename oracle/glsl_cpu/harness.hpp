@@ -83,4 +83,35 @@ extern "C" void gsr_render(const void* attr_in, uint64_t n, const uint32_t* boun
     height = h;
     dispatch((w + 15) / 16, (h + 15) / 16, local_size[0], local_size[1], [] { main(); });
 }
+
+#elif defined(CS_SORT_HIST)
+// One histogram pass of the radix sort, Renderer.cpp:598-612: `num_workgroups` groups of 256, push constants
+// {g_num_elements, g_shift, g_num_workgroups, g_num_blocks_per_workgroup} (Renderer.h:52-57).
+extern "C" void gsr_radix_hist(const uint64_t* keys_in, uint32_t* hist, uint32_t num_elements, uint32_t shift, uint32_t num_workgroups,
+                               uint32_t blocks_per_workgroup, uint32_t subgroup_size) {
+    g_elements_in.bind(keys_in, num_elements);
+    g_histograms.bind(hist, size_t(256) * num_workgroups);
+    g_num_elements = num_elements;
+    g_shift = shift;
+    g_num_workgroups = num_workgroups;
+    g_num_blocks_per_workgroup = blocks_per_workgroup;
+    dispatch_workgroups(num_workgroups, local_size[0], subgroup_size, [] { main(); });
+}
+
+#elif defined(CS_SORT_SORT)
+// One scatter pass of the radix sort, Renderer.cpp:616-620: the same grid and push constants as the histogram pass before it.
+extern "C" void gsr_radix_scatter(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* payload_in, uint32_t* payload_out,
+                                  const uint32_t* hist, uint32_t num_elements, uint32_t shift, uint32_t num_workgroups,
+                                  uint32_t blocks_per_workgroup, uint32_t subgroup_size) {
+    g_elements_in.bind(keys_in, num_elements);
+    g_elements_out.bind(keys_out, num_elements);
+    g_payload_in.bind(payload_in, num_elements);
+    g_payload_out.bind(payload_out, num_elements);
+    g_histograms.bind(hist, size_t(256) * num_workgroups);
+    g_num_elements = num_elements;
+    g_shift = shift;
+    g_num_workgroups = num_workgroups;
+    g_num_blocks_per_workgroup = blocks_per_workgroup;
+    dispatch_workgroups(num_workgroups, local_size[0], subgroup_size, [] { main(); });
+}
 #endif
