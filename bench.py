@@ -695,7 +695,9 @@ def cpu_baseline(n, w, h, kind="S", gpu_frames=None, ply=None):
             reference_text = {"value": round(1.0 / dtr, 4), "unit": "frames/s", "cores": all_threads, "kind": "reference",
                               "sample": f"1 frame in {dtr:.1f} s: src/shaders/*.comp compiled for the CPU (oracle/build_ref.py), "
                                         "one scalar invocation per thread slot, prefix_sum.comp's ceil(log2 N)+1 passes as written, "
-                                        "std::stable_sort in place of the 8 radix passes",
+                                        + ("the 8 radix passes = sort/hist.comp + sort/sort.comp as written (workgroups emulated with one fiber per "
+                                           "invocation: barriers, shared arrays, 32-wide subgroup operations)" if rst.get("text_sort")
+                                           else "std::stable_sort in place of the 8 radix passes (instances beyond GS_REF_TEXT_SORT_MAX)"),
                               "max_abs_vs_port": float(np.abs(rst["image"] - ref_img).max())}
     except Exception as e:  # baseline garnish only: never fail the bench line over it
         reference_text = {"error": str(e)}

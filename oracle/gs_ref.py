@@ -1,5 +1,5 @@
 """ctypes binding of oracle/_ref/libgs_ref.so -- the reference's own shader text compiled for the CPU
-(oracle/build_ref.py).  TEST INFRASTRUCTURE ONLY, like gs_oracle.py: tests pin the restated oracle against it.
+(oracle/build_ref.py), the radix sort (sort/hist.comp, sort/sort.comp) included.  TEST INFRASTRUCTURE ONLY, like gs_oracle.py: tests pin the restated oracle against it.
 
 The library is built where /root/reference is mounted (the CPU container) and travels to the GPU box as a
 prebuilt file; available() says whether it is there.
@@ -102,9 +102,16 @@ def render(attr, boundaries, payload, width, height):
     return rgba
 
 
-def stages(verts, uniforms, cov=None):
+# Up to this many instances stages() sorts with the reference's own radix-sort text (sort/hist.comp + sort/sort.comp on the CPU
+# workgroup emulation: ~1.7 s per million keys); beyond it with std::stable_sort, which the text is pinned to
+# (tests/test_oracle_vs_ref.py::test_the_reference_radix_sort_text_*).  Config B (4.9 M instances) is inside.
+TEXT_SORT_MAX = int(os.environ.get("GS_REF_TEXT_SORT_MAX", 6_000_000))
+
+
+def stages(verts, uniforms, cov=None, text_sort=None):
     """Same dictionary as gs_oracle.stages, every stage computed by the reference's shader text.
-    cov: the load-time precomp_cov3d result, when the caller times the per-frame passes only."""
+    cov: the load-time precomp_cov3d result, when the caller times the per-frame passes only.
+    text_sort: True = the sort is the reference's radix-sort text too, False = std::stable_sort, None = by TEXT_SORT_MAX."""
     w, h = int(uniforms["width"][0]), int(uniforms["height"][0])
     tx, ty = (w + 15) // 16, (h + 15) // 16
     if cov is None:
@@ -112,8 +119,21 @@ def stages(verts, uniforms, cov=None):
     attr, tiles = preprocess(verts, cov, uniforms)
     prefix = inclusive_scan(tiles)
     keys, payload = duplicate(attr, prefix, tx)
-    skeys, spayload = sort_pairs(keys, payload)
+    if text_sort is None:
+        text_sort = len(keys) <= TEXT_SORT_MAX
+    skeys, spayload = radix_sort_pairs(keys, payload) if text_sort else sort_pairs(keys, payload)
     bounds = tile_boundary(skeys, tx * ty)
     img = render(attr, bounds, spayload, w, h)
     return dict(cov3d=cov, attr=attr, tiles=tiles, prefix=prefix, keys=keys, payload=payload,
-                sorted_keys=skeys, sorted_payload=spayload, boundaries=bounds, image=img)
+                sorted_keys=skeys, sorted_payload=spayload, boundaries=bounds, image=img, text_sort=bool(text_sort))
+
+
+def radix_sort_pairs(keys, payload, blocks_per_workgroup=32, subgroup_size=32):
+    """The reference's OWN radix sort: sort/hist.comp + sort/sort.comp run eight times with Renderer.cpp:598-629's grid, push
+    constants and buffer ping-pong (blocks_per_workgroup: Renderer.h:134-138; subgroup_size: sort.comp:46 assumes 32)."""
+    keys, payload = np.ascontiguousarray(keys, np.uint64).copy(), np.ascontiguousarray(payload, np.uint32).copy()
+    lib().gsr_radix_sort_pairs.restype = C.c_int
+    rc = lib().gsr_radix_sort_pairs(_p(keys), _p(payload), C.c_uint64(len(keys)), C.c_uint32(blocks_per_workgroup), C.c_uint32(subgroup_size))
+    if rc != 0:
+        raise ValueError("gsr_radix_sort_pairs: element count beyond the shaders' 32-bit range")
+    return keys, payload

@@ -72,6 +72,53 @@ def test_library_is_the_reference_text(ref):
         assert f"src/shaders/{name} sha256=" in src
 
 
+def _keys_of(pkg, oracle, ref, n, kind, w, h, seed=0):
+    verts = oracle.activate_records(pkg.synth.synth_records(n, seed=seed, kind=kind))
+    u = oracle.camera_uniforms(oracle.default_camera(), w, h)
+    cov = ref.cov3d(verts)
+    attr, tiles = ref.preprocess(verts, cov, u)
+    return ref.duplicate(attr, ref.inclusive_scan(tiles), (w + 15) // 16)
+
+
+def test_the_reference_radix_sort_text_is_executed_and_is_a_stable_sort(pkg, oracle, ref):
+    """src/shaders/sort/hist.comp + sort/sort.comp, compiled as written and run eight times with Renderer.cpp:598-629's grid, push
+    constants and ping-pong on the CPU workgroup emulation (barriers, shared arrays, subgroup operations, LDS atomics), must produce
+    what the per-frame checks and the restated oracle use in its place: a stable ascending sort of the 64-bit keys."""
+    assert "sort/hist.comp" in ref.sources() and "sort/sort.comp" in ref.sources()
+    rng = np.random.default_rng(5)
+    cases = {}
+    cases["config A's instances"] = _keys_of(pkg, oracle, ref, 10_000, "A", 256, 256)
+    # tie-heavy: 7 tiles x 3 depths, payload order must survive all eight passes
+    n = 50_000
+    cases["ties"] = ((rng.integers(0, 7, n).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 3, n).astype(np.uint64), np.arange(n, dtype=np.uint32))
+    for n in (0, 1, 2, 255, 256, 257, 8191, 8192, 8193, 65_537):  # around the workgroup (256) and the workgroup's share (32 x 256)
+        cases[f"ragged {n}"] = (rng.integers(0, 2**64, n, dtype=np.uint64), rng.integers(0, 2**32, n, dtype=np.uint32))
+    cases["all keys equal"] = (np.full(3000, 0x0000002A3F800000, np.uint64), np.arange(3000, dtype=np.uint32)[::-1].copy())
+    cases["descending"] = (np.arange(20_000, dtype=np.uint64)[::-1].copy() << np.uint64(20), np.arange(20_000, dtype=np.uint32))
+    assert len(cases["config A's instances"][0]) > 10_000
+    for name, (keys, payload) in cases.items():
+        want_k, want_p = ref.sort_pairs(keys, payload)
+        order = np.argsort(keys, kind="stable")
+        np.testing.assert_array_equal(want_k, keys[order], err_msg=name)  # (std::stable_sort itself against numpy's)
+        np.testing.assert_array_equal(want_p, payload[order], err_msg=name)
+        # 32: what sort.comp:46 assumes; 64: what an AMD device would hand it; 256 blocks per workgroup: the Apple build (Renderer.h:135)
+        for subgroup, blocks in ((32, 32), (64, 32), (32, 256)):
+            got_k, got_p = ref.radix_sort_pairs(keys, payload, blocks_per_workgroup=blocks, subgroup_size=subgroup)
+            np.testing.assert_array_equal(got_k, want_k, err_msg=f"{name}: keys, subgroup {subgroup}, {blocks} blocks")
+            np.testing.assert_array_equal(got_p, want_p, err_msg=f"{name}: payloads, subgroup {subgroup}, {blocks} blocks")
+
+
+def test_the_reference_radix_sort_text_on_a_million_random_keys(ref):
+    rng = np.random.default_rng(6)
+    keys = rng.integers(0, 2**64, 1_000_000, dtype=np.uint64)
+    keys[0:700_000:7] = keys[3:700_003:7]  # and a hundred thousand exact duplicates
+    payload = np.arange(len(keys), dtype=np.uint32)
+    want_k, want_p = ref.sort_pairs(keys, payload)
+    got_k, got_p = ref.radix_sort_pairs(keys, payload)
+    np.testing.assert_array_equal(got_k, want_k)
+    np.testing.assert_array_equal(got_p, want_p)
+
+
 def test_config_a(pkg, oracle, ref):
     """BASELINE configs[0]: 10 k Gaussians, 256 x 256."""
     run_case(pkg, oracle, ref, 10_000, "A", 256, 256, seed=0)
