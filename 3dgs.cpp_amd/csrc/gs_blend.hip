@@ -12,6 +12,9 @@ namespace gs {
 #define GS_BLEND_ASM_ACCUMULATE 1  // the guarded mode's accumulate as one hand-written exec-masked block (A/B: 0 = the compiler's form;
                                    // the same block for the nine-instruction accumulate of the other modes measured +-0: not kept)
 #endif
+#ifndef GS_BLEND_ASM_LOOP
+#define GS_BLEND_ASM_LOOP 1  // round 5: the guarded mode's pair loop as ONE hand-written loop that keeps `alive` in exec (A/B: 0 = the loop below)
+#endif
 #ifndef GS_BLEND_SALU_DIET
 #define GS_BLEND_SALU_DIET 2  // 2: the pair loop's tail hand-written as well (round 4: blend -3..4 %: the scalar unit is a co-bottleneck)
 #endif
@@ -186,6 +189,100 @@ __device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist
     return brk;
 }
 
+// ---- the guarded mode's pair loop, hand-written (round 5) -------------------------------------------------------------
+// The compiler's form of the loop in blend_walk spends 26 vector and 18 scalar instructions per (entry, wave) pair, and the CU's
+// one scalar unit is a co-bottleneck.  Most of those scalar instructions move lane masks between VCC,
+// SGPR pairs and exec: `alive & ballot & ballot`, "is any lane left", save / restore exec around the accumulate, "did the last
+// pixel die".  This loop keeps ALIVE IN EXEC for its whole life instead:
+//   * the two tests of render.comp:68,78 are v_cmpx (exec &= condition): exec IS m2, "no lane" is one s_cbranch_execz;
+//   * under exec = m2 the break compare yields mk and the slice compare (into VCC: one s_cbranch_vccnz) yields sl directly;
+//   * T <- T (1 - alpha) is written in place for every lane of m2 -- a lane that breaks here is dead from here on, its T is never
+//     read again -- after the weight alpha T was formed from the old T; the accumulate runs under exec = m2 & ~mk (one s_andn2);
+//   * the wave's kept entries are staged COMPACTED (rank order), so the loop walks an address and a count: no s_ff1 / s_bitset0.
+// 25 vector + 8 scalar instructions per pair on the common path.  Same arithmetic, operation for operation, as the loop it
+// replaces (every product and sum of render.comp:66 rounded on its own, v_exp_f32, fl(o e), min, 1 - alpha, T (1 - alpha), the
+// fused accumulate of the guarded mode): the images of the two loops are bit-identical (tools/ab_image_check.py).
+// The loop returns to C++ (event = 1) only where the guard needs it: a lane of m2 inside the slice around 1e-4 (3 % of the
+// pairs); the pending pair is then finished by the caller (window tests, resolve_break, accumulate) and the loop re-entered.
+// Loaded records live in v[54:63] (a 128-bit operand's components cannot be named in inline asm): clobbered, the allocator
+// keeps out.  Hazards inside the string: v_exp_f32 -> its consumer (trans op, 1 state: the s_nop); none of the others apply
+// (no DPP / readlane / VMEM here; SALU and branch reads of VALU-written VCC / EXEC / SGPRs are interlocked).
+struct PairLoopEvent {
+    uint64_t m2, mk, sl;   // lanes that evaluated exp; of those: T (1 - alpha) < 1e-4 with the fast exp; inside the slice
+    float w;               // alpha * T(before) -- valid in the lanes of m2 (the entry's colour is re-read from the slab: 3 % of the pairs)
+};
+// slab_addr: LDS byte address of the next entry's {c00' c01' c11' o} (the other two planes 1024 and 2048 bytes behind it);
+// rem: pairs left in the chunk MINUS ONE.  Returns 0 when the chunk is exhausted or alive == 0, 1 with `ev` filled (rem then
+// still counts the pending pair, slab_addr is already past it).
+__device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_t& rem, uint64_t& alive, const float fx, const float fy, float& T,
+                                                    float& c0, float& c1, float& c2, PairLoopEvent& ev) {
+    uint32_t event;
+    uint64_t saved;
+    const float k1e4 = 0.0001f;
+    // (the count is wave-uniform, but the compiler may carry it in a VGPR -- it feeds VALU code too -- and an inline-asm SGPR operand
+    //  is not legalised for it: "illegal VGPR to SGPR copy")
+    uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[alive]\n"
+        ".Lgs_pair_%=:\n\t"
+        "ds_read_b128 v[54:57], %[addr]\n\t"
+        "ds_read_b128 v[58:61], %[addr] offset:1024\n\t"
+        "ds_read_b64 v[62:63], %[addr] offset:2048\n\t"
+        "v_add_u32 %[addr], 16, %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v58, v58, %[fx]\n\t"           // dx = u - x   (the loaded registers double as temporaries)
+        "v_sub_f32 v59, v59, %[fy]\n\t"           // dy = v - y
+        "v_mul_f32 v54, v54, v58\n\t"             // c00' dx
+        "v_mul_f32 v56, v56, v59\n\t"             // c11' dy
+        "v_mul_f32 v54, v58, v54\n\t"             // c00' dx dx
+        "v_mul_f32 v56, v59, v56\n\t"             // c11' dy dy
+        "v_mul_f32 v55, v55, v58\n\t"             // c01' dx
+        "v_add_f32 v54, v54, v56\n\t"             // s
+        "v_mul_f32 v55, v55, v59\n\t"             // c01' dx dy
+        "v_add_f32 v54, v55, v54\n\t"             // power = s + c01' dx dy            (render.comp:66)
+        "v_cmpx_ge_f32 vcc, 0, v54\n\t"           // power <= 0 (false for NaN)        (render.comp:68)
+        "v_cmpx_nlt_f32 vcc, v54, v63\n\t"        // !(power < alpha cut)              (render.comp:78, decided on power)
+        "s_cbranch_execz .Lgs_skip_%=\n\t"
+        "v_mul_f32 v56, 0x3fb8aa3b, v54\n\t"
+        "v_exp_f32 v56, v56\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32 v56, v57, v56\n\t"             // o e'
+        "v_min_f32 v56, 0x3f7d70a4, v56\n\t"      // alpha = min(0.99, .)             (render.comp:77)
+        "v_sub_f32 v55, 1.0, v56\n\t"             // 1 - alpha
+        "v_mul_f32 %[w], v56, %[T]\n\t"           // alpha T: the weight of this entry (the T of before)
+        "v_mul_f32 %[T], %[T], v55\n\t"           // test_T = T (1 - alpha), in place
+        "v_cmp_gt_f32 %[mk], %[k1e4], %[T]\n\t"    // test_T < 1e-4                     (render.comp:83)
+        "v_cmp_eq_u32_sdwa vcc, %[T], %[slice] src0_sel:WORD_1 src1_sel:DWORD\n\t"  // ... and is any of them inside the guard's slice?
+        "s_cbranch_vccnz .Lgs_event_%=\n\t"
+        "s_andn2_b64 exec, exec, %[mk]\n\t"
+        "v_fmac_f32 %[c0], v60, %[w]\n\t"          // render.comp:87 (the guarded mode's fused form)
+        "v_fmac_f32 %[c1], v61, %[w]\n\t"
+        "v_fmac_f32 %[c2], v62, %[w]\n\t"
+        "s_andn2_b64 %[alive], %[alive], %[mk]\n\t"
+        "s_cbranch_scc0 .Lgs_done_%=\n"            // every pixel of the quadrant has saturated
+        ".Lgs_skip_%=:\n\t"
+        "s_mov_b64 exec, %[alive]\n\t"
+        "s_add_u32 %[rem], %[rem], -1\n\t"         // carry = there was another pair
+        "s_cbranch_scc1 .Lgs_pair_%=\n"
+        ".Lgs_done_%=:\n\t"
+        "s_mov_b32 %[ev], 0\n\t"
+        "s_branch .Lgs_exit_%=\n"
+        ".Lgs_event_%=:\n\t"
+        "s_mov_b64 %[m2], exec\n\t"
+        "s_mov_b64 %[sl], vcc\n\t"
+        "s_mov_b32 %[ev], 1\n"
+        ".Lgs_exit_%=:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [T] "+v"(T), [addr] "+v"(slab_addr), [alive] "+s"(alive), [rem] "+s"(left),
+          [ev] "=&s"(event), [mk] "=&s"(ev.mk), [m2] "=&s"(ev.m2), [sl] "=&s"(ev.sl), [sv] "=&s"(saved),
+          [w] "=&v"(ev.w)
+        : [fx] "v"(fx), [fy] "v"(fy), [k1e4] "s"(k1e4), [slice] "s"(kGuardSlice)
+        : "vcc", "scc", "memory", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    rem = left;
+    return event;
+}
+
 // One pass of a wave over its tile's list: returns false if the quadrant has to be re-rendered exactly (GUARD only; c0..c2
 // are then meaningless).  slab: this wave's three planes of 64 float4 {c00' c01' c11' o} {u v r g} {b, cut, -, -} --
 // plane-major keeps the staging ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets
@@ -198,6 +295,11 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                                            const float rx0, const float ry0, uint64_t alive, float& c0, float& c1, float& c2,
                                            uint32_t& resolved, bool& table_ready) {
     const uint2* __restrict__ exptab = exptab_rw;
+#if defined(GS_BLEND_STATS)
+    constexpr bool kAsmLoop = false;  // (the work counters live in the compiler's form of the loop)
+#else
+    constexpr bool kAsmLoop = GUARD && EXP == 1 && !CONTRACT && GS_BLEND_ASM_LOOP != 0;
+#endif
     float T = 1.0f;
     c0 = c1 = c2 = 0.0f;
     uint32_t npairs = 0;                       // GUARD: (entry, wave) pairs evaluated so far (bounds every lane's step count)
@@ -253,6 +355,7 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
         if (bm == 0) continue;
         const uint64_t bm0 = bm;      // GUARD: the chunk's kept entries (bm is consumed below)
         const uint32_t kbase = npairs;  // GUARD: how many entries the list of kept entries held before this chunk
+        uint32_t rank = 0;              // GUARD: this lane's entry is the chunk's rank-th kept one
         if (GUARD) {
             // abandon: set where a break decision had to be resolved (see there); more pairs than the coarse window allows for
             npairs += (uint32_t)__popcll(bm);
@@ -261,10 +364,80 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                 break;
             }
             // the wave's list of kept entries, for resolve_break: the Gaussian id of the chunk's r-th kept entry at kbase + r
-            const uint32_t at = kbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            const uint32_t at = kbase + rank;
             if (keep && at < kGuardList) klist[at] = g_cur;
             __builtin_amdgcn_wave_barrier();
         }
+        if constexpr (kAsmLoop) {
+            // the kept entries staged in rank order: the hand-written loop walks an address and a count
+            if (keep) {
+                slab[0][rank] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
+                slab[1][rank] = cur.uv;
+                slab[2][rank] = make_float4(cur.bc.x, cut, 0.0f, 0.0f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n_kept = (uint32_t)__popcll(bm0);
+            uint32_t rem = n_kept - 1u;
+            uint32_t slab_addr = (uint32_t)(uintptr_t)&slab[0][0];  // (the low half of a flat LDS pointer is the LDS offset)
+            PairLoopEvent ev;
+            while (blend_pair_loop(slab_addr, rem, alive, fx, fy, T, c0, c1, c2, ev) != 0) {
+                // a lane of ev.m2 has its T (1 - alpha) -- now in T -- inside the slice around 1e-4: the pending pair is finished here
+                const float test_T = T;
+                uint64_t mk = ev.mk;
+                uint64_t amb = ev.sl & __builtin_amdgcn_ballot_w64(test_T >= kGuardLo && test_T < kGuardHi);  // the coarse window
+                if (amb != 0) {  // ... and the lane's own?  (S: the finished chunks; T_cs / test_T - 1: this chunk, this step included)
+                    const float S_now = fminf(kGuardSMax, S + __builtin_fmaf(T_cs * 1.00001f, __builtin_amdgcn_rcpf(test_T), -1.0f));
+                    const float W = __builtin_fmaf((float)npairs, kGuardStep, S_now * kGuardUnit);
+                    const bool inside_own = test_T >= __builtin_fmaf(-0.0001f, W, 0.0001f) && test_T < __builtin_fmaf(0.0001f, W, 0.0001f);
+                    amb &= __builtin_amdgcn_ballot_w64(inside_own);
+                }
+                if (amb != 0) {  // ask the reference
+                    if (!table_ready) {  // the wave's copy of libm's table, on first use
+                        if (lane < 32) {
+                            const uint64_t v = kExpfTab[lane];
+                            exptab_rw[lane] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        table_ready = true;
+                    }
+                    mk &= ~amb;
+                    const uint32_t pos = kbase + (n_kept - 1u - rem);  // the tested entry in the list of kept entries
+                    do {
+                        const int a = __ffsll((unsigned long long)amb) - 1;
+                        amb &= amb - 1;
+                        const float fxa = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fx), a));
+                        const float fya = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fy), a));
+                        // past the list's end, or one pixel too many: the quadrant is abandoned at the next chunk and re-rendered exactly
+                        if (pos >= kGuardList || resolved >= kGuardMaxResolves) abandon = true;
+                        else if (resolve_break(klist, pos, rec, exptab, lane, fxa, fya)) mk |= 1ull << a;
+                        ++resolved;
+                    } while (amb != 0);
+                }
+                {   // render.comp:87 for the lanes that are kept and do not break (T already holds T (1 - alpha))
+                    // (wave-uniform, but after resolve_break the compiler no longer proves it: made scalar by hand)
+                    mk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mk >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mk);
+                    uint64_t updm = ev.m2 & ~mk;
+                    updm = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(updm >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)updm);
+                    const uint32_t at = n_kept - 1u - rem;  // the pending pair's slot in the slab
+                    const float er = slab[1][at].z, eg = slab[1][at].w, eb = slab[2][at].x;
+                    uint64_t saved;
+                    asm volatile("s_and_saveexec_b64 %[sv], %[um]\n\t"
+                                 "v_fmac_f32 %[c0], %[r], %[w]\n\t"
+                                 "v_fmac_f32 %[c1], %[g], %[w]\n\t"
+                                 "v_fmac_f32 %[c2], %[b], %[w]\n\t"
+                                 "s_or_b64 exec, exec, %[sv]"
+                                 : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [sv] "=&s"(saved)
+                                 : [um] "s"(updm), [w] "v"(ev.w), [r] "v"(er), [g] "v"(eg), [b] "v"(eb)
+                                 : "scc");
+                }
+                alive &= ~mk;
+                if (alive == 0 || rem == 0) break;
+                --rem;
+            }
+        } else {
         // conic pre-scaled once per entry: (-c00/2, -c01, -c11/2).  Scaling by a power of two commutes with every
         // rounding below, so power is bit-identical to render.comp:66 evaluated as written while the per-pixel body
         // loses the -0.5 multiply
@@ -423,6 +596,7 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
 #endif
             }
         }
+        }  // (the compiler's form of the pair loop)
         if (alive == 0) break;
         if (GUARD) {  // chunk end: sum a/(1 - a) over the chunk's steps <= T_start / T_end - 1 (1e-5: v_rcp_f32's ULP)
             S += __builtin_fmaf(T_cs * 1.00001f, __builtin_amdgcn_rcpf(T), -1.0f);
