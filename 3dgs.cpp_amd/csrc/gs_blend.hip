@@ -199,7 +199,7 @@ __device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist
 //   * T <- T (1 - alpha) is written in place for every lane of m2 -- a lane that breaks here is dead from here on, its T is never
 //     read again -- after the weight alpha T was formed from the old T; the accumulate runs under exec = m2 & ~mk (one s_andn2);
 //   * the wave's kept entries are staged COMPACTED (rank order), so the loop walks an address and a count: no s_ff1 / s_bitset0.
-// 25 vector + 8 scalar instructions per pair on the common path.  Same arithmetic, operation for operation, as the loop it
+// 25 vector + 7 scalar instructions per pair on the common path, two branches (the event test and the back edge).  Same arithmetic, operation for operation, as the loop it
 // replaces (every product and sum of render.comp:66 rounded on its own, v_exp_f32, fl(o e), min, 1 - alpha, T (1 - alpha), the
 // fused accumulate of the guarded mode): the images of the two loops are bit-identical (tools/ab_image_check.py).
 // The loop returns to C++ (event = 1) only where the guard needs it: a lane of m2 inside the slice around 1e-4 (3 % of the
@@ -207,6 +207,14 @@ __device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist
 // Loaded records live in v[54:63] (a 128-bit operand's components cannot be named in inline asm): clobbered, the allocator
 // keeps out.  Hazards inside the string: v_exp_f32 -> its consumer (trans op, 1 state: the s_nop); none of the others apply
 // (no DPP / readlane / VMEM here; SALU and branch reads of VALU-written VCC / EXEC / SGPRs are interlocked).
+#ifndef GS_BLEND_EXECZ_BRANCH
+#define GS_BLEND_EXECZ_BRANCH 0  // 0: no s_cbranch_execz -- the 6 % of the pairs no pixel keeps run the exp section with exec = 0 (every VALU a no-op,
+                                 // mk = sl = 0); 1 (A/B) the branch.  Config B, serial blend: 168 -> 166.5 us
+#endif
+#ifndef GS_BLEND_TAIL_CSELECT
+#define GS_BLEND_TAIL_CSELECT 1  // 1: "the last pixel died" folds into the count (s_cselect: the loop ends at its own test) instead of a branch
+                                 // of its own; with the line above 168 -> 166 us (alone: neutral)
+#endif
 struct PairLoopEvent {
     uint64_t m2, mk, sl;   // lanes that evaluated exp; of those: T (1 - alpha) < 1e-4 with the fast exp; inside the slice
     float w;               // alpha * T(before) -- valid in the lanes of m2 (the entry's colour is re-read from the slab: 3 % of the pairs)
@@ -243,7 +251,9 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
         "v_add_f32 v54, v55, v54\n\t"             // power = s + c01' dx dy            (render.comp:66)
         "v_cmpx_ge_f32 vcc, 0, v54\n\t"           // power <= 0 (false for NaN)        (render.comp:68)
         "v_cmpx_nlt_f32 vcc, v54, v63\n\t"        // !(power < alpha cut)              (render.comp:78, decided on power)
+#if GS_BLEND_EXECZ_BRANCH
         "s_cbranch_execz .Lgs_skip_%=\n\t"
+#endif
         "v_mul_f32 v56, 0x3fb8aa3b, v54\n\t"
         "v_exp_f32 v56, v56\n\t"
         "s_nop 0\n\t"
@@ -260,7 +270,11 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
         "v_fmac_f32 %[c1], v61, %[w]\n\t"
         "v_fmac_f32 %[c2], v62, %[w]\n\t"
         "s_andn2_b64 %[alive], %[alive], %[mk]\n\t"
+#if GS_BLEND_TAIL_CSELECT
+        "s_cselect_b32 %[rem], %[rem], 0\n"
+#else
         "s_cbranch_scc0 .Lgs_done_%=\n"            // every pixel of the quadrant has saturated
+#endif
         ".Lgs_skip_%=:\n\t"
         "s_mov_b64 exec, %[alive]\n\t"
         "s_add_u32 %[rem], %[rem], -1\n\t"         // carry = there was another pair
