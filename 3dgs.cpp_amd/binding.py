@@ -58,7 +58,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
            "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_set_blend_contraction", "gs_get_timing_totals",
-           "gs_get_frame_intervals", "gs_get_stats", "gs_debug_download", "gs_debug_expf_scan", "gs_renderer_stream",
+           "gs_get_frame_intervals", "gs_get_stats", "gs_poll_stats", "gs_debug_download", "gs_debug_expf_scan", "gs_renderer_stream",
            "gs_dist_unique_id", "gs_dist_create", "gs_dist_rank", "gs_dist_world", "gs_dist_pose_count",
            "gs_dist_broadcast_scene", "gs_dist_broadcast_scene_ex", "gs_dist_verify", "gs_dist_destroy"]
 
@@ -316,6 +316,13 @@ class Renderer:
         st = FrameStats()
         _check(lib().gs_get_stats(self._h, C.byref(st)))
         return st
+
+    def poll_stats(self):
+        """(stats of the most recently retired frame, frames retired so far) without waiting (gs_poll_stats)."""
+        st = FrameStats()
+        n = C.c_uint64()
+        _check(lib().gs_poll_stats(self._h, C.byref(st), C.byref(n)))
+        return st, n.value
 
     def stage(self, name, uniforms=None):
         """Download a stage buffer of the last frame as a numpy array."""

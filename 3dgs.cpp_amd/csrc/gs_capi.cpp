@@ -131,7 +131,16 @@ struct gs_scene {
         cov3d.alloc(6 * n);
         if (reinterpret_cast<uintptr_t>(blob) % 64 != 0)
             throw Error(GS_ERR_INVALID, "the scene blob must be 64-byte aligned (SH blocks are read as 16-byte vectors)");
-        make_spatial_copy();
+        // best effort: the copy is an optimisation (a second blob in HBM, a host-side sort); if any of its allocations fails the
+        // scene simply renders from the blob as loaded (advisor, round 4)
+        try {
+            make_spatial_copy();
+        } catch (const std::bad_alloc&) {
+            drop_spatial_copy();
+        } catch (const Error& e) {
+            if (e.code != GS_ERR_NOMEM) throw;
+            drop_spatial_copy();
+        }
         gs::launch_cov3d(render_blob(), cov3d.p, static_cast<uint32_t>(n), static_cast<uint32_t>(gs::blob_stride(n)), nullptr);
         acut.alloc(n);
         DevBuf<uint32_t> beyond;
@@ -144,6 +153,12 @@ struct gs_scene {
         unit_opacity = flag == 0;
     }
 
+    void drop_spatial_copy() {
+        (void)hipGetLastError();  // (a failed hipMalloc leaves its error behind)
+        perm.release();
+        spatial_blob.release();
+        std::fprintf(stderr, "[gs3d] no memory for the scene's copy in spatial order: rendering from the blob as loaded\n");
+    }
     // Spatial order: Morton code of the position (21 bits per axis over the scene's bounding box), ties by id.
     void make_spatial_copy() {
         uint64_t min_n = 4ull << 20;
@@ -682,7 +697,8 @@ struct gs_renderer {
     // decisions, its pixels to rounding noise; 2 libm's expf restated in binary64 -- the reference's bits; 0 pipeline polynomial, 1 v_exp_f32
     int exp_mode = 3;
     // a scene that holds an opacity > 1 is outside the guard's premises: blended with mode 2's arithmetic instead
-    int blend_exp_mode() const { return exp_mode == 3 && !scene->unit_opacity ? 2 : exp_mode; }
+    // (with the contractions on, mode 3 runs as mode 1 whatever the scene holds: there is nothing to guard -- gs3d_hip.h)
+    int blend_exp_mode() const { return exp_mode == 3 && !contract && !scene->unit_opacity ? 2 : exp_mode; }
     bool contract = false;       // the three FMA contractions GLSL permits in render.comp:66,87 (gs_set_blend_contraction); default: as written
     int min_bin_shift = 3;       // GS_BIN_SHIFT: log2 of the default bin edge in tiles (8 x 8 tiles)
     // GS_L1_DENSE_MIN: scenes of at least this many Gaussians hand level 1 the dense lists of visible Gaussians (measured
@@ -716,6 +732,7 @@ struct gs_renderer {
     uint32_t redo_chain = 0;     // consecutive re-runs since a frame last retired cleanly: the runaway guard
     double total_ms[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t total_frames = 0;
+    uint64_t lifetime_frames = 0;  // frames retired since creation (gs_poll_stats)
     // completion-to-completion intervals of consecutive frames (the frame time a consumer sees with frames in flight)
     static constexpr size_t kIntervalRing = 8192;
     std::vector<float> intervals;
@@ -860,7 +877,6 @@ struct gs_renderer {
         FrameSlot& sl = slots[frames_enqueued % kSlots];
         FrameBuffers& fb = sets[frames_enqueued % num_sets];
         hipStream_t stream = fb.stream;
-        last_set = &fb;
         hipEvent_t* ev = sl.ev;
         const uint32_t n = static_cast<uint32_t>(scene->n);
         const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
@@ -880,6 +896,8 @@ struct gs_renderer {
             if (at_level >= kGlobalLevel) fb.ensure_depth_order();
             if (at_level == gs::kBinSlabLevel && !fb.slabs.p) fb.slabs.alloc(static_cast<size_t>(gs::kSlabCapacity) * gs::kSlabDescBytes);
         }
+        // (after any drain above: retiring may re-run frames through enqueue, which would leave another set's buffers here)
+        last_set = &fb;
         const BinGeometry geo = bin_geometry(tx, ty);
         const int lv = frame_level();
         const bool bin_local = lv < kGlobalLevel;
@@ -1198,6 +1216,7 @@ struct gs_renderer {
                             st.ms_tile_boundary, st.ms_render, st.ms_total};
         for (int k = 0; k < 7; ++k) total_ms[k] += v[k];
         ++total_frames;
+        ++lifetime_frames;
         {   // frames on different streams may finish out of order: measure against the latest completion so far
             const uint64_t idx = frames_enqueued - pending;  // this frame
             if (prev_retired) {
@@ -1502,6 +1521,25 @@ int gs_get_stats(gs_renderer* r, gs_frame_stats* out) {
             out->blend_redo = c.blend_redo;
             out->blend_resolved = c.blend_resolved;
         }
+    });
+}
+
+int gs_poll_stats(gs_renderer* r, gs_frame_stats* out, uint64_t* frames_retired) {
+    return guarded([&] {
+        if (!r || !out) throw Error(GS_ERR_INVALID, "null argument");
+        HIP_CHECK(hipSetDevice(r->scene->device));
+        while (r->pending > 0) {  // retire what has completed, without waiting for what has not
+            const hipError_t e = hipEventQuery(r->oldest().done);
+            if (e == hipErrorNotReady) break;
+            HIP_CHECK(e);
+            r->retire_oldest();
+        }
+        *out = r->last;
+        out->num_gaussians = r->scene->n;
+        out->instance_capacity = r->capacity;
+        out->retries = r->retries;
+        out->blend_redo = out->blend_resolved = 0;
+        if (frames_retired) *frames_retired = r->lifetime_frames;
     });
 }
 

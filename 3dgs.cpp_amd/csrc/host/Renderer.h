@@ -50,8 +50,11 @@ private:
     gs_renderer* renderer = nullptr;
     std::atomic<bool> running{true};
     bool mouseCaptured = false;
-    void* d_bgra = nullptr;
+    // the "swapchain": one B8G8R8A8 image per frame in flight (a swapchain has two or three; Swapchain.cpp:22-28)
+    static constexpr int kMaxImages = 3;
+    void* d_bgra[kMaxImages] = {nullptr, nullptr, nullptr};
     uint64_t bgraBytes = 0;
+    int framesInFlight = 1;  // run(): GS_FRAMES_IN_FLIGHT (default 3) unless frames are dumped or metrics logged per frame
     std::vector<uint8_t> h_bgra;
     int fpsCounter = 0;
     std::chrono::high_resolution_clock::time_point lastFpsTime = std::chrono::high_resolution_clock::now();

@@ -123,7 +123,8 @@ Renderer::Renderer(VulkanSplatting::RendererConfiguration configuration_)
 
 Renderer::~Renderer() {
     gs_renderer_destroy(renderer);
-    if (d_bgra) (void)hipFree(d_bgra);
+    for (void* p : d_bgra)
+        if (p) (void)hipFree(p);
 }
 
 void Renderer::initialize() {  // Renderer.cpp:19-31 without Vulkan / swapchain / GUI / pipelines
@@ -133,6 +134,15 @@ void Renderer::initialize() {  // Renderer.cpp:19-31 without Vulkan / swapchain 
     scene->load(device);
     check(gs_renderer_create(scene->handle(), &renderer));
     metricsCsv = env_or("GS_METRICS_CSV", "");
+    // The reference has one frame in flight (VulkanContext.h:6) and reads the frame's timestamps back before the next one
+    // (Renderer.cpp:428-450).  Here a loop that neither dumps frames nor logs per-frame metrics keeps up to three frames queued
+    // (each into its own image, presented in order): GS_FRAMES_IN_FLIGHT, default 3; 1 = the reference's behaviour.
+    framesInFlight = 1;
+    if (!window->wantsFrame() && metricsCsv.empty()) {
+        const std::string v = env_or("GS_FRAMES_IN_FLIGHT", "3");
+        framesInFlight = std::max(1, std::min(kMaxImages, std::atoi(v.c_str())));
+    }
+    check(gs_set_frames_in_flight(renderer, framesInFlight));
 }
 
 void Renderer::handleInput() {  // Renderer.cpp:33-83 (GUI capture checks drop out: there is no GUI)
@@ -179,17 +189,21 @@ void Renderer::draw() {  // Renderer.cpp:366-426: handleInput, updateUniforms, t
     gs_uniforms u{};
     check(gs_camera_uniforms(&cam, width, height, &u));
     const uint64_t need = static_cast<uint64_t>(width) * height * 4;
-    if (need > bgraBytes) {  // the "swapchain image": B8G8R8A8_UNORM (Swapchain.cpp:22-28)
+    if (need > bgraBytes) {  // the "swapchain images": B8G8R8A8_UNORM (Swapchain.cpp:22-28), one per frame in flight
         check(gs_synchronize(renderer));
-        if (d_bgra) (void)hipFree(d_bgra);
-        if (hipMalloc(&d_bgra, need) != hipSuccess) throw std::runtime_error("Failed to allocate the frame image");
+        for (int k = 0; k < framesInFlight; ++k) {
+            if (d_bgra[k]) (void)hipFree(d_bgra[k]);
+            d_bgra[k] = nullptr;
+            if (hipMalloc(&d_bgra[k], need) != hipSuccess) throw std::runtime_error("Failed to allocate the frame image");
+        }
         bgraBytes = need;
     }
-    check(gs_render(renderer, &u, nullptr, static_cast<uint8_t*>(d_bgra)));
+    void* const image = d_bgra[frameIndex % static_cast<uint64_t>(framesInFlight)];
+    check(gs_render(renderer, &u, nullptr, static_cast<uint8_t*>(image)));
     if (window->wantsFrame()) {
         check(gs_synchronize(renderer));
         h_bgra.resize(need);
-        if (hipMemcpy(h_bgra.data(), d_bgra, need, hipMemcpyDeviceToHost) != hipSuccess)
+        if (hipMemcpy(h_bgra.data(), image, need, hipMemcpyDeviceToHost) != hipSuccess)
             throw std::runtime_error("Failed to read back the frame image");
         window->present(h_bgra.data(), width, height);
     } else {
@@ -200,7 +214,8 @@ void Renderer::draw() {  // Renderer.cpp:366-426: handleInput, updateUniforms, t
 
 void Renderer::retrieveTimestamps() {  // Renderer.cpp:85-100; QueryManager::parseResults names
     gs_frame_stats st{};
-    check(gs_get_stats(renderer, &st));
+    if (framesInFlight > 1) check(gs_poll_stats(renderer, &st, nullptr));  // the newest FINISHED frame: nothing waits
+    else check(gs_get_stats(renderer, &st));
     metrics = {{"preprocess", st.ms_preprocess}, {"prefix_sum", st.ms_prefix_sum}, {"preprocess_sort", st.ms_preprocess_sort},
                {"sort", st.ms_sort},             {"tile_boundary", st.ms_tile_boundary}, {"render", st.ms_render}};
     instances = st.num_instances;

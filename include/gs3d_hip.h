@@ -249,6 +249,11 @@ int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, 
 int gs_get_frame_intervals(gs_renderer* r, float* out_ms, uint64_t capacity, uint64_t* n_out, int reset);
 /* Renderer::retrieveTimestamps (Renderer.cpp:85-100) for the last frame; synchronizes. */
 int gs_get_stats(gs_renderer* r, gs_frame_stats* out);
+/* The same WITHOUT waiting, for a frame loop that keeps frames in flight (gs_set_frames_in_flight): retires the queued frames
+ * that have completed (growing the buffers and re-running on overflow, like gs_synchronize) and returns the statistics of the
+ * most recently retired one (all zero before the first).  *frames_retired (nullable) = frames retired since the renderer was
+ * created.  blend_redo / blend_resolved are not read here (0). */
+int gs_poll_stats(gs_renderer* r, gs_frame_stats* out, uint64_t* frames_retired);
 /* Copy a stage buffer of the last frame to host memory; synchronizes.  The per-tile lists live bin-major in HBM;
  * GS_STAGE_SORTED_GID / _SORTED_TILE / _RANGES present them laid end to end in tile order, i.e. as the reference's
  * sorted payload, the tile half of its sorted keys and its tileBoundaryBuffer. */

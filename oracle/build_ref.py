@@ -32,6 +32,14 @@ on glsl_cpu/workgroup.hpp (one fiber per invocation).  Two more syntactic rewrit
 The per-frame checks use gsr_sort_pairs (std::stable_sort: what eight stable LSD passes over all 64 key bits amount to);
 tests/test_oracle_vs_ref.py pins the shader text's result to it.
 
+The reference's HOST arithmetic runs too (gsr_load_records, gsr_update_uniforms, gsr_camera_translate): the text of
+GSScene.cpp:17-24 (struct VertexStorage), the body of GSScene::load's conversion loop (GSScene.cpp:37-58), GSScene.h's struct Vertex,
+Renderer.h's struct UniformBuffer and struct Camera, and Renderer::updateUniforms (Renderer.cpp:719-754) whole are cut out of
+the files where they lie and compiled verbatim against glsl_cpu/glm_stub.hpp (glm is absent here: the stub restates the inside
+of the glm calls that text makes, citing glm's files; the order of calls, constants, sign flips and the double / float mix are
+the reference's own text).  The objects that text touches -- plyFile, verteces, swapchain, camera, uniformBuffer -- are supplied
+by the generated harness with the members it uses.
+
 Usage: python oracle/build_ref.py [--reference /root/reference] [--keep-generated DIR]
 """
 import argparse
@@ -91,6 +99,115 @@ def glsl_to_cpp(text, shader_dir, workgroup=False):
     return "\n".join(out)
 
 
+def braces(text, start):
+    """Index just past the brace that closes the one at text[start]."""
+    assert text[start] == "{"
+    depth = 0
+    for k in range(start, len(text)):
+        if text[k] == "{":
+            depth += 1
+        elif text[k] == "}":
+            depth -= 1
+            if depth == 0:
+                return k + 1
+    raise RuntimeError("unbalanced braces")
+
+
+def cut(text, pattern, what):
+    """The text from the match of `pattern` (which ends at an opening brace) through the matching closing brace (+ a following ';')."""
+    m = re.search(pattern, text)
+    if not m:
+        raise RuntimeError(f"build_ref: cannot find {what} in the reference")
+    end = braces(text, m.end() - 1)
+    if text[end:end + 1] == ";":
+        end += 1
+    return text[m.start():end], text[m.end():end - 1 - (1 if text[end - 1] == ";" else 0)]
+
+
+def host_text_to_cpp(reference):
+    """cs_host.cpp: the reference's loader loop and camera uniforms, verbatim, against glm_stub.hpp."""
+    def read(rel):
+        with open(os.path.join(reference, rel)) as f:
+            return f.read()
+    scene_cpp, scene_h = read("src/GSScene.cpp"), read("src/GSScene.h")
+    rend_cpp, rend_h = read("src/Renderer.cpp"), read("src/Renderer.h")
+    vertex_storage, _ = cut(scene_cpp, r"struct VertexStorage\s*\{", "struct VertexStorage")
+    vertex, _ = cut(scene_h, r"struct Vertex\s*\{", "struct Vertex")
+    uniform_buffer, _ = cut(rend_h, r"struct alignas\(16\) UniformBuffer\s*\{", "struct UniformBuffer")
+    camera, _ = cut(rend_h, r"struct Camera\s*\{", "struct Camera")
+    _, load_loop = cut(scene_cpp, r"for \(auto i = 0; i < header\.numVertices; i\+\+\)\s*\{", "GSScene::load's loop")
+    _, update_uniforms = cut(rend_cpp, r"void Renderer::updateUniforms\(\)\s*\{", "Renderer::updateUniforms")
+    return f"""// GENERATED by oracle/build_ref.py from the reference's sources where they lie -- never committed.
+#define NDEBUG 1  // (the loop asserts that the PLY's normals are zero: GSScene.cpp:55-57)
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include "glm_stub.hpp"
+namespace ref_host {{
+// ---- GSScene.cpp:17-24
+{vertex_storage}
+// ---- GSScene.h:41-46
+{vertex}
+// ---- Renderer.h:21-29
+{uniform_buffer}
+// ---- Renderer.h:40-50
+{camera}
+static_assert(sizeof(VertexStorage) == 62 * 4 && sizeof(Vertex) == 60 * 4 && sizeof(UniformBuffer) == 160, "record layouts");
+// what the text below touches, with the members it uses
+struct FakeIfstream {{
+    const char* p;
+    void read(char* dst, size_t n) {{ std::memcpy(dst, p, n); p += n; }}
+    bool is_open() const {{ return true; }}
+    bool eof() const {{ return false; }}
+}};
+struct FakeSwapchain {{ struct {{ uint32_t width, height; }} swapchainExtent; }};
+struct FakeUniformBuffer {{
+    void* dst;
+    void upload(const void* src, size_t n, size_t) {{ std::memcpy(dst, src, n); }}
+}};
+static Camera camera;
+static FakeSwapchain swapchain_object, *swapchain = &swapchain_object;
+static FakeUniformBuffer uniform_object, *uniformBuffer = &uniform_object;
+
+// ---- Renderer.cpp:719-754, verbatim
+void updateUniforms() {{{update_uniforms}}}
+
+extern "C" void gsr_load_records(const float* records, uint64_t n, float* vertices) {{
+    FakeIfstream plyFile{{reinterpret_cast<const char*>(records)}};
+    Vertex* verteces = reinterpret_cast<Vertex*>(vertices);
+    struct {{ uint64_t numVertices; }} header{{n}};
+    for (uint64_t i = 0; i < header.numVertices; i++) {{
+        // ---- GSScene.cpp:37-58, verbatim
+{load_loop}
+    }}
+}}
+// cam: position[3], rotation (w, x, y, z), fov, near, far  (the gs_camera of include/gs3d_hip.h)
+static void set_camera(const float* cam) {{
+    camera.position = glm::vec3(cam[0], cam[1], cam[2]);
+    camera.rotation = glm::quat(cam[3], cam[4], cam[5], cam[6]);
+    camera.fov = cam[7];
+    camera.nearPlane = cam[8];
+    camera.farPlane = cam[9];
+}}
+extern "C" void gsr_update_uniforms(const float* cam, uint32_t width, uint32_t height, void* out160) {{
+    set_camera(cam);
+    swapchain_object.swapchainExtent.width = width;
+    swapchain_object.swapchainExtent.height = height;
+    uniform_object.dst = out160;
+    updateUniforms();
+}}
+extern "C" void gsr_camera_translate(const float* cam, const float* t, float* position_out) {{
+    set_camera(cam);
+    camera.translate(glm::vec3(t[0], t[1], t[2]));  // Renderer.h:47-49
+    position_out[0] = camera.position.x;
+    position_out[1] = camera.position.y;
+    position_out[2] = camera.position.z;
+}}
+}}  // namespace ref_host
+"""
+
+
 def sha256(path):
     with open(path, "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()
@@ -128,6 +245,14 @@ def main():
             obj = os.path.join(tmp, f"cs_{name}.o")
             subprocess.check_call(["g++", *CXXFLAGS, "-I", compat, "-c", src, "-o", obj])
             objs.append(obj)
+        for rel in ("src/GSScene.cpp", "src/GSScene.h", "src/Renderer.cpp", "src/Renderer.h"):
+            provenance.append(f"{rel} sha256={sha256(os.path.join(args.reference, rel))}")
+        hsrc = os.path.join(gen_dir, "cs_host.cpp")
+        with open(hsrc, "w") as f:
+            f.write(host_text_to_cpp(args.reference))
+        hobj = os.path.join(tmp, "cs_host.o")
+        subprocess.check_call(["g++", *[x for x in CXXFLAGS if x != "-std=c++17"], "-std=c++20", "-I", compat, "-c", hsrc, "-o", hobj])
+        objs.append(hobj)
         prov = os.path.join(gen_dir, "provenance.cpp")
         with open(prov, "w") as f:
             lines = "\\n".join(provenance)

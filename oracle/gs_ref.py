@@ -137,3 +137,36 @@ def radix_sort_pairs(keys, payload, blocks_per_workgroup=32, subgroup_size=32):
     if rc != 0:
         raise ValueError("gsr_radix_sort_pairs: element count beyond the shaders' 32-bit range")
     return keys, payload
+
+
+# ---- the reference's HOST arithmetic, its own text compiled against glsl_cpu/glm_stub.hpp (build_ref.py: host_text_to_cpp) ----
+def load_records(records):
+    """GSScene::load's conversion loop (GSScene.cpp:37-58), verbatim: (n, 62) PLY records -> (n, 60) GSScene::Vertex floats."""
+    records = np.ascontiguousarray(records, np.float32).reshape(-1, 62)
+    out = np.zeros((len(records), 60), np.float32)
+    lib().gsr_load_records(_p(records), C.c_uint64(len(records)), _p(out))
+    return out
+
+
+def _cam10(cam):
+    """gs_camera (position[3], rotation wxyz, fov, near, far) as ten floats."""
+    c = np.zeros(10, np.float32)
+    c[0:3] = np.asarray(cam["position"], np.float32).reshape(-1)[:3]
+    c[3:7] = np.asarray(cam["rotation"], np.float32).reshape(-1)[:4]
+    c[7], c[8], c[9] = float(cam["fov"][0]), float(cam["near_plane"][0]), float(cam["far_plane"][0])
+    return c
+
+
+def update_uniforms(cam, width, height):
+    """Renderer::updateUniforms (Renderer.cpp:719-754), verbatim: the 160-byte uniform block as raw bytes."""
+    out = np.zeros(160, np.uint8)
+    lib().gsr_update_uniforms(_p(_cam10(cam)), C.c_uint32(width), C.c_uint32(height), _p(out))
+    return out
+
+
+def camera_translate(cam, t):
+    """Renderer::Camera::translate (Renderer.h:47-49), verbatim: the new position."""
+    out = np.zeros(3, np.float32)
+    tt = np.asarray(t, np.float32)
+    lib().gsr_camera_translate(_p(_cam10(cam)), _p(tt), _p(out))
+    return out
