@@ -62,6 +62,25 @@ def test_unchanged_reference_viewer_headless(pkg, oracle, gpu, tmp_path):
         np.testing.assert_array_equal(read_ppm(tmp_path / f), ref)
 
 
+def test_viewer_keeps_frames_in_flight_when_nothing_is_dumped(pkg, gpu, tmp_path):
+    """lib3dgs_cpp's run loop queues up to three frames (GS_FRAMES_IN_FLIGHT, default 3) when neither frames are dumped nor per-frame metrics
+    logged; the frames themselves are the renderer's frames-in-flight path (test_frames_in_flight_match_serial).  Here: the loop runs, retires
+    every frame and reports its rate; with GS_FRAMES_IN_FLIGHT=1 it is the reference's serial loop."""
+    exe = os.path.join(PKG, "viewer_ref")
+    if not os.path.exists(exe):
+        pytest.skip("viewer_ref was not built (the reference tree was not mounted at build time)")
+    rec = pkg.synth.synth_records(20000, seed=3, kind="A")
+    ply = str(tmp_path / "scene.ply")
+    pkg.synth.write_ply(ply, rec)
+    for fif in ("3", "1"):
+        env = dict(os.environ, GS_FRAMES="300", GS_FRAMES_IN_FLIGHT=fif)
+        env.pop("GS_DUMP_DIR", None)
+        env.pop("GS_METRICS_CSV", None)
+        out = subprocess.run([exe, "--no-gui", "--width", "640", "--height", "360", ply], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "error" not in out.stderr.lower(), out.stderr
+
+
 def test_embedded_host_mode(pkg, oracle, gpu, tmp_path):
     exe = os.path.join(PKG, "embedded_host_test")
     rec = pkg.synth.synth_records(5000, seed=13, kind="A")
