@@ -57,7 +57,7 @@ SYMBOLS = ["gs_last_error", "gs_device_count", "gs_read_ply", "gs_activate_recor
            "gs_scene_num_vertices", "gs_scene_quantize_sh", "gs_scene_sh_bits", "gs_scene_download_vertex_range",
            "gs_scene_download_vertices", "gs_scene_download_cov3d",
            "gs_scene_destroy", "gs_renderer_create", "gs_renderer_destroy", "gs_camera_uniforms",
-           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_set_blend_contraction", "gs_get_timing_totals",
+           "gs_render", "gs_render_host", "gs_synchronize", "gs_set_timing", "gs_set_frames_in_flight", "gs_set_sort_path", "gs_set_exp_mode", "gs_set_graph_mode", "gs_set_blend_lockstep", "gs_get_blend_lockstep", "gs_set_blend_contraction", "gs_get_timing_totals",
            "gs_get_frame_intervals", "gs_get_stats", "gs_poll_stats", "gs_debug_download", "gs_debug_expf_scan", "gs_renderer_stream",
            "gs_dist_unique_id", "gs_dist_create", "gs_dist_rank", "gs_dist_world", "gs_dist_pose_count",
            "gs_dist_broadcast_scene", "gs_dist_broadcast_scene_ex", "gs_dist_verify", "gs_dist_destroy"]
@@ -293,6 +293,18 @@ class Renderer:
     def set_graph_mode(self, enabled):
         """Replay frames as captured HIP graphs (gs_set_graph_mode)."""
         _check(lib().gs_set_graph_mode(self._h, C.c_int(int(bool(enabled)))))
+
+    def set_blend_lockstep(self, mode):
+        """-1 automatic (measured), 0 off, 1 on: the tile's four waves take every chunk together (gs_set_blend_lockstep)."""
+        _check(lib().gs_set_blend_lockstep(self._h, C.c_int(int(mode))))
+
+    def blend_lockstep(self):
+        """(the setting the next frame runs with, whether the measurement has settled)."""
+        settled = C.c_int(0)
+        now = lib().gs_get_blend_lockstep(self._h, C.byref(settled))
+        if now < 0:
+            _check(now)
+        return bool(now), bool(settled.value)
 
     def set_sort_path(self, mode):
         """0 automatic, 1 global depth order, 2 bin-local (gs_set_sort_path)."""

@@ -26,7 +26,8 @@ struct SlabDesc {
     uint32_t kmin;             // bucket of a key = (key - kmin) >> sh
     int32_t sh;
     uint32_t b_lo, b_hi;       // the slab's buckets
-    uint32_t pad[2];
+    uint32_t ready;            // k_bin_queue: the epoch of the launch that wrote this descriptor (published with an agent-scope release)
+    uint32_t pad;
     uint32_t cur[64];          // per tile of the bin: where this slab's entries go in the list buffer
 };
 static_assert(sizeof(SlabDesc) == 288, "descriptor layout");
@@ -43,6 +44,7 @@ struct BuildArgs {
     uint32_t capacity;
     SlabDesc* slabs;       // k_bin_slabs -> k_slab_work (level 4)
     uint32_t slab_capacity;
+    uint32_t epoch;        // k_bin_queue: see BinLaunch::slab_epoch
 };
 
 // candidate's tile box clipped to the bin, in bin-local tile coordinates (upper bounds exclusive), packed like l1_item's
@@ -419,6 +421,12 @@ struct FastLayout {
 // slab; bins of <= MAXC it processes itself like MODE 0.  MODE 2 (k_slab_work, workgroups striding over the descriptors)
 // streams the bin's records once more, compacts the slab's members into LDS, orders them like a small bin and appends them at
 // the descriptor's cursors.  The slabs are depth-ordered and each is (depth, id)-ordered inside: so is every tile's list.
+// MODE 3 (k_bin_queue, round 5): both in ONE launch of persistent workgroups that take items from a queue -- first the bins, fullest
+// first (a bin beyond MAXC is planned, its descriptors published with an agent-scope release; a smaller one is processed whole), then
+// the slabs as they become ready.  510 bins and 297 slabs of uneven size on 256 one-per-CU workgroups left the sum of the workgroup
+// times at 0.55 (bins) and 0.45 (slabs) of 256 CUs x span with a launch each (profiles/r04_level2_counts_ab.txt); the queue packs them.
+// A workgroup waits for a slab only once every bin has been CLAIMED, i.e. is being worked on by a resident workgroup: no deadlock
+// whatever the residency; the wait ends when the descriptor is ready or every bin is done and it is not.
 template <int ROUNDS, int MODE = 0>
 __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     constexpr bool SLABS = MODE != 0;
@@ -445,17 +453,21 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     constexpr int kMaxSlabs = 16;
     __shared__ uint32_t g_cur[SLABS ? 64 : 1], t_tot[SLABS ? 64 : 1];  // a slab's list cursors; per-tile totals of the bin
     __shared__ uint32_t slab_first[SLABS ? kMaxSlabs + 1 : 1];         // first bucket of each slab
-    __shared__ uint32_t cnt2[MODE == 1 ? kMaxSlabs : 1][64];           // instances per slab and tile
+    __shared__ uint32_t cnt2[(MODE == 1 || MODE == 3) ? kMaxSlabs : 1][64];           // instances per slab and tile
     __shared__ uint32_t s_fill;
+    __shared__ uint16_t q_order[MODE == 3 ? 1024 : 1];  // MODE 3: the on-screen bins, fullest first
+    __shared__ uint32_t q_item, q_planned;              // the claimed item; how many bins are beyond MAXC (they are planned, and first)
 
     BUILD_ROW(MODE == 2 ? 1023u : blockIdx.x);
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;  // (MODE 3 re-derives them per item: see there)
     // one workgroup per ON-SCREEN bin (the grid is bins_x * bins_y: with the padding of the bin grid in it, workgroups
     // that exit at once upset the dispatcher's placement and a few CUs end up with three of the real ones)
-    const uint32_t bin = ((blockIdx.x / a.g.bins_x) << a.g.grid_shift) | (blockIdx.x % a.g.bins_x);
+    auto screen_bin = [&](uint32_t i) { return ((i / a.g.bins_x) << a.g.grid_shift) | (i % a.g.bins_x); };
+    uint32_t bin = screen_bin(MODE == 3 ? 0u : blockIdx.x);
+    bool slab_item = MODE == 2;  // MODE 3: the item at hand is a depth slab (block-uniform)
     BUILD_T(0);
     uint32_t c_total = 0, off = 0;
-    if constexpr (MODE != 2) {  // this bin's count and offset (the padded grid has <= 1024 = THREADS bins)
+    auto bin_extent = [&]() {  // this bin's count and offset (the padded grid has <= 1024 = THREADS bins)
         const uint32_t nb = 1u << (2 * a.g.grid_shift);
         const uint32_t v = (uint32_t)tid < nb ? a.bin_count[tid] : 0u;
         uint32_t tb, tm;
@@ -466,15 +478,16 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         // load wrapped in a readfirstlane loop with a full s_waitcnt, i.e. serialised
         c_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)tm);
         off = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
-    }
-    if ((uint64_t)off + c_total > a.capacity) c_total = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
-    if (c_total > kMaxInBin) {
-        if (tid == 0) atomicOr(&a.counters->overflow, 2u);
-        c_total = 0;
-    }
+        if ((uint64_t)off + c_total > a.capacity) c_total = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
+        if (c_total > kMaxInBin) {
+            if (tid == 0) atomicOr(&a.counters->overflow, 2u);
+            c_total = 0;
+        }
+    };
+    if constexpr (MODE == 0 || MODE == 1) bin_extent();
     if (tid == 0) s_flag = 0;
     BUILD_T(1);
-#define multi (MODE == 2 ? true : (MODE == 1 ? c_total > (uint32_t)MAXC : false))  /* block-uniform */
+#define multi (MODE == 2 ? true : (MODE == 1 ? c_total > (uint32_t)MAXC : (MODE == 3 ? (slab_item || c_total > (uint32_t)MAXC) : false)))  /* block-uniform */
     // c: the candidates in LDS (the whole bin, or the current slab of it); rounds / wbase follow it
     uint32_t c = multi ? 0u : c_total;
     int rounds = (int)((c + THREADS - 1) / THREADS);  // block-uniform, <= ROUNDS
@@ -482,9 +495,21 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // of two) and the hardware's bounds check in place of branches (reads past the run return 0)
     typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 #define recs uniform_rsrc(a.cand + (size_t)kCandWords * off, c_total * 12u)  /* rebuilt from scalars at every use: see uniform_rsrc */
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint64_t lt_mask = (1ull << lane) - 1ull;
     // list element e belongs to wave e / (64 * rounds), round (e / 64) % rounds, lane e % 64
     uint32_t wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
+    // The thread's coordinates made opaque again (round 5): every phase below is a fully unrolled loop over ROUNDS elements whose
+    // offsets all derive from tid; left to itself the compiler computes the offsets of ALL phases up front, keeps them alive across
+    // the body and spills them (k_slab_work: 108 bytes of scratch per lane -> 0 with one refresh per slab; k_bin_queue 372 -> 140).
+    auto refresh = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        tid = t;
+        lane = t & (WAVE - 1);
+        w = t / WAVE;
+        lt_mask = (1ull << lane) - 1ull;
+        wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
+    };
     // One stable LSD pass over (s_key, s_pay) in place: digit = `db` (<= 9) bits of (s_key - sub) at `shift`; the pass
     // writes s_key - sub back (the first pass of a sort normalises the keys to the bin's smallest, the others pass sub = 0).
     auto radix_pass = [&](int shift, int db, uint32_t sub) {
@@ -738,7 +763,9 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // ---- a bin beyond MAXC: its depth range, the bucket histogram, the per-tile totals, the slabs
     uint32_t n_slabs = 1, g_kmin = 0;
     int g_sh = 0;
-    if constexpr (MODE == 1) if (multi) {
+    bool published = false;  // MODE 3: this bin wrote descriptors (they need the release before the bin counts as done)
+    auto plan_bin = [&]() {
+    if constexpr (MODE == 1 || MODE == 3) if (!slab_item && multi) {
         uint32_t lo = 0xFFFFFFFFu, hi = 0u;
         for (uint32_t base = 0; base < c_total; base += 8 * THREADS) {  // pass 0: the keys' range (eight loads in flight)
             uint32_t k[8];
@@ -879,21 +906,42 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         __syncthreads();
         const uint32_t dbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seg0);
         if (dbase + n_slabs <= a.slab_capacity) {
+            // MODE 3 hands the descriptors to workgroups of the SAME launch, possibly on another XCD (whose L2 is not coherent with this
+            // one): every word goes out as a relaxed agent-scope atomic store (written through, sc1) and is read the same way on the
+            // other side; then every wave's stores retired -> barrier -> the ready words, the same way.  No L2 write-back, no fence:
+            // an agent-scope release here (buffer_wbl2) flushes the whole XCD's dirty lines -- the other frames' records, lists and
+            // pixels included -- once per planned bin, and cost 6 % of the frame rate with three frames in flight.
+            auto put = [&](uint32_t* p, uint32_t v) {
+                if constexpr (MODE == 3) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *p = v;
+            };
             for (uint32_t k = 0; k < n_slabs; ++k) {
                 SlabDesc* d = a.slabs + dbase + k;
-                if (tid < 64) d->cur[tid] = g_cur[tid] + cnt2[k][tid];
+                if (tid < 64) put(&d->cur[tid], g_cur[tid] + cnt2[k][tid]);
                 if (tid == 64) {
-                    d->off = off;
-                    d->c_total = c_total;
-                    d->kmin = g_kmin;
-                    d->sh = g_sh;
-                    d->b_lo = slab_first[k];
-                    d->b_hi = slab_first[k + 1];
+                    put(&d->off, off);
+                    put(&d->c_total, c_total);
+                    put(&d->kmin, g_kmin);
+                    put(reinterpret_cast<uint32_t*>(&d->sh), (uint32_t)g_sh);
+                    put(&d->b_lo, slab_first[k]);
+                    put(&d->b_hi, slab_first[k + 1]);
                 }
+            }
+            if constexpr (MODE == 3) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    for (uint32_t k = 0; k < n_slabs; ++k)
+                        __hip_atomic_store(&a.slabs[dbase + k].ready, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and they have left before this bin counts as planned
+                }
+                published = true;
             }
         }
         n_slabs = 0;  // nothing more to do for this bin here
     }
+    };
+    if constexpr (MODE == 1) plan_bin();
     // (a lambda, not a loop body: with a loop around it -- even one of a constant single trip -- the register allocator
     // of hipcc 7.2 spills 45 instead of 19 registers in k_bin_fast<12>)
     auto slab_body = [&](const uint32_t slab) {
@@ -968,6 +1016,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         if (attempt == 0) BUILD_T(2);
         sort_by_key(attempt == 0);
         if (attempt == 0) BUILD_T(8);
+        refresh();
         // ---- ties.  Candidates of equal depth must follow each other by Gaussian id (what the reference's stable sort of
         // (tile, depth) keys over index-ordered input gives).  Equal keys are adjacent now.  The element that STARTS a run of
         // equal keys measures the run (at most 64 more); all elements fetch their ids (a gather inside the bin's own record
@@ -1061,6 +1110,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     }
 #undef recs
     BUILD_T(3);
+    refresh();
     // ---- the candidates' tile boxes inside the bin (they rode along in the payload), and the (chunk, tile) counts
     const uint32_t nch = (c + WAVE - 1) / WAVE;
     {
@@ -1148,6 +1198,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     }
     __syncthreads();
     BUILD_T(6);
+    refresh();
     // ---- fill.  Chunks are independent now: the table holds where each chunk's run starts in every tile's list.
     const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.sorted_gid, 0, a.capacity * 4u, 0x27000);
     for (uint32_t ch = w; ch < nch; ch += NW) {
@@ -1185,11 +1236,107 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         slab_body(0u);
     } else if constexpr (MODE == 1) {
         if (n_slabs != 0) slab_body(0u);  // a bin of <= MAXC: one slab, the whole of it
+    } else if constexpr (MODE == 3) {
+        const uint32_t n_bins = a.g.bins_x * a.g.bins_y;  // <= 1024
+        {   // the on-screen bins, fullest first: rank by counting (<= 1024 broadcast reads per thread, once per workgroup)
+            uint32_t* const cnt = smem;  // (LDS is free until the first item starts)
+            const uint32_t mine = (uint32_t)tid < n_bins ? a.bin_count[screen_bin((uint32_t)tid)] : 0u;
+            cnt[tid] = mine;
+            if (tid == 0) q_planned = 0;
+            __syncthreads();
+            if (mine > (uint32_t)MAXC) atomicAdd(&q_planned, 1u);
+            if ((uint32_t)tid < n_bins) {
+                uint32_t before = 0;
+                for (uint32_t j = 0; j < n_bins; ++j) {
+                    const uint32_t v = cnt[j];
+                    before += (v > mine || (v == mine && j < (uint32_t)tid)) ? 1u : 0u;
+                }
+                q_order[before] = (uint16_t)tid;
+            }
+            __syncthreads();
+        }
+        const uint32_t n_planned = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_planned);  // the first n_planned items of the queue
+        for (;;) {
+            __syncthreads();  // the previous item is done with LDS and the shared variables
+            refresh();  // (per item)
+            if (tid == 0) {
+                q_item = atomicAdd(&a.counters->q_head, 1u);
+                s_flag = 0;
+            }
+            __syncthreads();
+            const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_item);
+            if (item < n_bins) {  // ---- a bin
+                slab_item = false;
+                published = false;
+                bin = screen_bin((uint32_t)q_order[item]);
+                bin_extent();
+                c = multi ? 0u : c_total;
+                rounds = (int)((c + THREADS - 1) / THREADS);
+                wbase = (uint32_t)w * (uint32_t)rounds * WAVE;
+                n_slabs = 1;
+                g_kmin = 0;
+                g_sh = 0;
+                plan_bin();
+            } else {
+            // ---- a depth slab: wait until its descriptor is ready, or until every bin is done and it is not (then there is none)
+            const uint32_t d = item - n_bins;
+            if (tid == 0) {
+                uint32_t have = 0;
+                if (d < a.slab_capacity) {
+                    for (uint32_t spin = 0;; ++spin) {
+                        if (__hip_atomic_load(&a.slabs[d].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch) {
+                            have = 1;
+                            break;
+                        }
+                        if (__hip_atomic_load(&a.counters->q_bins_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_planned) {
+                            // every bin beyond MAXC has been planned (they head the queue, so this is early in the launch: nobody
+                            // waits for the slowest ordinary bin), and every descriptor was released before its bin counted: one
+                            // more look decides
+                            have = __hip_atomic_load(&a.slabs[d].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch ? 1u : 0u;
+                            break;
+                        }
+                        if (spin > (1u << 20)) {  // (~ seconds: never expected; rather the global path than a hung queue)
+                            atomicOr(&a.counters->overflow, 2u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(64);
+                    }
+                }
+                q_item = have;
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane((int)q_item) == 0) break;  // no such slab: the queue is drained
+            SlabDesc* desc = a.slabs + d;
+            slab_item = true;
+            // (written through by another workgroup of this launch: read past this CU's L1, word by word -- see plan_bin)
+            auto get = [&](uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            off = (uint32_t)__builtin_amdgcn_readfirstlane((int)get(&desc->off));
+            c_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)get(&desc->c_total));
+            g_kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)get(&desc->kmin));
+            g_sh = __builtin_amdgcn_readfirstlane((int)get(reinterpret_cast<uint32_t*>(&desc->sh)));
+            if (tid < 64) g_cur[tid] = get(&desc->cur[tid]);
+            if (tid == 0) {
+                slab_first[0] = get(&desc->b_lo);
+                slab_first[1] = get(&desc->b_hi);
+            }
+            __syncthreads();
+            c = 0;
+            n_slabs = 1;
+            }
+            // a bin beyond MAXC counts as planned whatever became of it (descriptors written, or an overflow flagged): its ready
+            // words have left (plan_bin waits for them) before the count
+            if (!slab_item && item < n_planned) {
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(&a.counters->q_bins_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (n_slabs != 0) slab_body(0u);  // (one call site for both kinds of item: the body is large)
+        }
     } else {
         const uint32_t n_desc = min(a.counters->slabs, a.slab_capacity);
         for (uint32_t d = blockIdx.x; d < n_desc; d += gridDim.x) {
             const SlabDesc* desc = a.slabs + d;
             __syncthreads();  // the previous slab is done with LDS and the shared variables
+            refresh();  // (per slab)
             off = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc->off);
             c_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc->c_total);
             g_kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc->kmin);
@@ -1224,6 +1371,8 @@ template <> __global__ __launch_bounds__(1024, 4) void k_bin_fast<16>(BuildArgs 
 #endif
 __global__ __launch_bounds__(1024, 4) void k_bin_slabs(BuildArgs a) { bin_fast_body<GS_SLAB_ROUNDS, 1>(a); }
 __global__ __launch_bounds__(1024, 4) void k_slab_work(BuildArgs a) { bin_fast_body<GS_SLAB_ROUNDS, 2>(a); }
+// the two of them as one launch of persistent workgroups over a queue of bins, then slabs
+__global__ __launch_bounds__(1024, 4) void k_bin_queue(BuildArgs a) { bin_fast_body<GS_SLAB_ROUNDS, 3>(a); }
 
 template <int R2, int THREADS, bool SORT>
 static hipError_t build_prepare() {  // > 64 KiB of dynamic LDS needs the attribute
@@ -1264,6 +1413,9 @@ hipError_t bin_prepare_device() {  // once per device (gs_renderer::init)
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_work), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_queue), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t)));
     return e;
 }
 
@@ -1288,6 +1440,7 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
     a.capacity = b.capacity;
     a.slabs = reinterpret_cast<SlabDesc*>(b.slabs);
     a.slab_capacity = b.slab_capacity;
+    a.epoch = b.slab_epoch;
     const uint32_t bins = b.bins_x * b.bins_y;  // on-screen bins: the kernels map the block index onto the padded grid
     const bool sort = level < kBinSortLevels;
     if (sort && b.bin_shift <= 3) {  // bins of 4 x 4 or 8 x 8 tiles: the all-in-LDS kernel, sized by the level
@@ -1295,7 +1448,10 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
         else if (level == 1) hipLaunchKernelGGL(k_bin_fast<8>, dim3(bins), dim3(1024), FastLayout<8>::WORDS * sizeof(uint32_t), s, a);
         else if (level == 2) hipLaunchKernelGGL(k_bin_fast<12>, dim3(bins), dim3(1024), FastLayout<12>::WORDS * sizeof(uint32_t), s, a);
         else if (level == 3) hipLaunchKernelGGL(k_bin_fast<16>, dim3(bins), dim3(1024), FastLayout<16>::WORDS * sizeof(uint32_t), s, a);
-        else {
+        else if (b.slab_epoch != 0) {
+            // one launch: persistent workgroups (one per CU's worth of LDS; more than fit simply find the queue drained) over bins, then slabs
+            hipLaunchKernelGGL(k_bin_queue, dim3(bins < kQueueWorkGroups ? bins : kQueueWorkGroups), dim3(1024), FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t), s, a);
+        } else {
             hipLaunchKernelGGL(k_bin_slabs, dim3(bins), dim3(1024), FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t), s, a);
             hipLaunchKernelGGL(k_slab_work, dim3(kSlabWorkGroups), dim3(1024), FastLayout<GS_SLAB_ROUNDS>::WORDS * sizeof(uint32_t), s, a);
         }

@@ -558,6 +558,7 @@ struct FrameBuffers {
     DevBuf<uint32_t> sorted;              // [capacity + 4] per-tile lists, bin-major
     DevBuf<uint32_t> ranges;              // [T][2]
     DevBuf<uint8_t> slabs;                // depth-slab descriptors (level 4; allocated on first use)
+    uint32_t slab_epoch = 0;              // k_bin_queue: one value per launch on these descriptors (BinLaunch::slab_epoch)
     DevBuf<gs::Counters> counters;
     // HIP-graph replay (gs_set_graph_mode): the frame's fixed-shape launches captured once per configuration
     DevBuf<gs::FrameParams> params;
@@ -566,8 +567,9 @@ struct FrameBuffers {
         int level = -1, hw_exp = 0, contract = 1, bin_shift = -1;
         uint32_t width = 0, height = 0, capacity = 0;
         const void *tile_order = nullptr, *ranges = nullptr, *sh16 = nullptr;
+        bool lockstep = false;
         bool operator==(const GraphKey& o) const {
-            return level == o.level && hw_exp == o.hw_exp && contract == o.contract && bin_shift == o.bin_shift && width == o.width && height == o.height &&
+            return lockstep == o.lockstep && level == o.level && hw_exp == o.hw_exp && contract == o.contract && bin_shift == o.bin_shift && width == o.width && height == o.height &&
                    capacity == o.capacity && tile_order == o.tile_order && ranges == o.ranges && sh16 == o.sh16;
         }
     } graph_key;
@@ -650,6 +652,8 @@ struct FrameSlot {
     bool timed = false;
     int level = 0;  // the depth-order level this frame ran at (gs_renderer::level)
     int bin_shift = 3;
+    bool lockstep = false;      // the blend's lockstep setting this frame ran with
+    uint32_t tune_round = 0;    // ... and the tuner's round it belongs to (samples of an earlier round are ignored)
 };
 
 struct gs_renderer {
@@ -700,6 +704,52 @@ struct gs_renderer {
     // (with the contractions on, mode 3 runs as mode 1 whatever the scene holds: there is nothing to guard -- gs3d_hip.h)
     int blend_exp_mode() const { return exp_mode == 3 && !contract && !scene->unit_opacity ? 2 : exp_mode; }
     bool contract = false;       // the three FMA contractions GLSL permits in render.comp:66,87 (gs_set_blend_contraction); default: as written
+    // The blend's LOCKSTEP (gs_blend.hip): the four waves of a tile take every chunk of its list together, so that their gathers of the
+    // same records meet in L1.  Worth +25 % of the blend on trained-like scenes (L1-miss-bound: T(6e6) 505 -> 378 us; T(1e6) with three
+    // frames in flight 2 675 -> 3 575 frames/s), -9 % on the S scenes (pair-loop-bound).  Nothing the renderer knows up front tells the
+    // two apart, so it MEASURES: a few frames each way (the blend's own span; the frames are bit-identical either way), keeps the
+    // faster, and looks again every 4096 frames or when the frame's shape changes.  GS_BLEND_LOCKSTEP=0 / 1 (or gs_set_blend_lockstep)
+    // pins it; the tuner then rests.
+    struct BlendTuner {
+        static constexpr int kSkip = 2, kSamples = 6;   // per setting: frames ignored after the switch, frames measured
+        static constexpr uint32_t kPeriod = 4096;       // settled frames between two looks
+        int forced = -1;        // -1 automatic, 0 / 1 pinned
+        int phase = 0;          // 0: measuring lockstep off, 1: measuring on, 2: settled
+        bool choice = false;    // the settled setting
+        uint32_t round = 1, seen = 0, settled_frames = 0;
+        double sum[2] = {0, 0};
+        int count[2] = {0, 0};
+        bool current() const { return forced >= 0 ? forced != 0 : (phase == 2 ? choice : phase == 1); }
+        void restart() {
+            phase = 0;
+            seen = settled_frames = 0;
+            sum[0] = sum[1] = 0;
+            count[0] = count[1] = 0;
+            ++round;
+        }
+        // a retired frame's blend time (ms), the setting and the round it ran with
+        void sample(float ms, bool lockstep, uint32_t frame_round) {
+            if (forced >= 0) return;
+            if (phase == 2) {
+                if (++settled_frames >= kPeriod) restart();
+                return;
+            }
+            if (frame_round != round || lockstep != (phase == 1) || !(ms > 0.0f)) return;  // a frame of before the switch
+            if (++seen <= (uint32_t)kSkip) return;
+            sum[phase] += ms;
+            if (++count[phase] < kSamples) return;
+            if (phase == 0) {
+                phase = 1;
+                seen = 0;
+                ++round;
+            } else {
+                choice = sum[1] / count[1] < sum[0] / count[0];
+                phase = 2;
+                settled_frames = 0;
+                ++round;
+            }
+        }
+    } tuner;
     int min_bin_shift = 3;       // GS_BIN_SHIFT: log2 of the default bin edge in tiles (8 x 8 tiles)
     // GS_L1_DENSE_MIN: scenes of at least this many Gaussians hand level 1 the dense lists of visible Gaussians (measured
     // A/B, profiles/r03_l1_dense_lists_ab.txt: 6 M Gaussians +2 % one frame at a time, +2..7 % with three in flight --
@@ -708,6 +758,8 @@ struct gs_renderer {
     // one frame at a time, +0.5 % with three in flight).  The GPU tests set it to 0 for small scenes.
     uint64_t dense_min = 4u << 20;
     bool debug_levels = std::getenv("GS_DEBUG_LEVELS") != nullptr;
+    bool level2_queue = !(std::getenv("GS_L2_QUEUE") && std::atoi(std::getenv("GS_L2_QUEUE")) == 0);
+    uint32_t tuned_w = 0, tuned_h = 0;  // the frame shape the blend tuner last looked at
     // GS_DEBUG_STALLS=<ms>: a gs_render call that keeps the host longer than this is reported on stderr with the time each of
     // its parts took (wait for a free frame slot; the launches of each pass; the closing event records) -- how the runtime's
     // own hiccups (profiles/r05_stall_*.txt) are told from the renderer's
@@ -760,6 +812,7 @@ struct gs_renderer {
     }
 
     void init() {
+        if (const char* e = std::getenv("GS_BLEND_LOCKSTEP")) tuner.forced = std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0);
         HIP_CHECK(hipSetDevice(scene->device));
         HIP_CHECK(gs::bin_prepare_device());
         if (std::getenv("GS_DEBUG_OCCUPANCY")) gs::bin_debug_occupancy();
@@ -894,10 +947,19 @@ struct gs_renderer {
             const int at_level = frame_level();
             fb.ranges.ensure(2 * nt);
             if (at_level >= kGlobalLevel) fb.ensure_depth_order();
-            if (at_level == gs::kBinSlabLevel && !fb.slabs.p) fb.slabs.alloc(static_cast<size_t>(gs::kSlabCapacity) * gs::kSlabDescBytes);
+            if (at_level == gs::kBinSlabLevel && !fb.slabs.p) {
+                fb.slabs.alloc(static_cast<size_t>(gs::kSlabCapacity) * gs::kSlabDescBytes);
+                HIP_CHECK(hipMemset(fb.slabs.p, 0, fb.slabs.n));  // no descriptor carries a launch's epoch yet
+            }
         }
         // (after any drain above: retiring may re-run frames through enqueue, which would leave another set's buffers here)
         last_set = &fb;
+        if (u.width != tuned_w || u.height != tuned_h) {  // another frame shape: the blend tuner looks again
+            tuned_w = u.width;
+            tuned_h = u.height;
+            tuner.restart();
+        }
+        const bool lockstep = tuner.current();
         const BinGeometry geo = bin_geometry(tx, ty);
         const int lv = frame_level();
         const bool bin_local = lv < kGlobalLevel;
@@ -979,6 +1041,13 @@ struct gs_renderer {
                 b.capacity = capacity;
                 b.slabs = fb.slabs.p;
                 b.slab_capacity = fb.slabs.p ? gs::kSlabCapacity : 0u;
+                // level 4 as one launch over a queue of bins and slabs -- not in a captured frame (a replay repeats its arguments,
+                // and a descriptor is ready when it holds THIS launch's epoch); GS_L2_QUEUE=0: the two launches of round 4
+                b.slab_epoch = 0;
+                if (level2_queue && !fp && lv == gs::kBinSlabLevel) {
+                    if (++fb.slab_epoch == 0) ++fb.slab_epoch;
+                    b.slab_epoch = fb.slab_epoch;
+                }
                 b.tiles_x = tx;
                 b.tiles_y = ty;
                 b.bins_x = geo.bins_x;
@@ -1005,7 +1074,7 @@ struct gs_renderer {
                 HIP_CHECK(hipStreamWaitEvent(bstream, fb.prep_done, 0));
             }
             gs::launch_blend(fb.ranges.p, fb.sorted.p, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
-                             fused_counters ? sl.h_counters : nullptr, blend_exp_mode(), contract, fp, bstream);
+                             fused_counters ? sl.h_counters : nullptr, blend_exp_mode(), contract, fp, lockstep, bstream);
             lap(7);
         };
         depth_order = bin_local ? nullptr : fb.dvals[1].p;
@@ -1026,6 +1095,7 @@ struct gs_renderer {
             key.tile_order = tile_order.p;
             key.ranges = fb.ranges.p;
             key.sh16 = sv.sh16;
+            key.lockstep = lockstep;
             if (!fb.graph_exec || !(key == fb.graph_key)) {  // first frame of this configuration: capture its launches
                 fb.drop_graph();
                 hipGraph_t graph = nullptr;
@@ -1060,6 +1130,8 @@ struct gs_renderer {
 
         sl.level = lv;
         sl.bin_shift = geo.bin_shift;
+        sl.lockstep = lockstep;
+        sl.tune_round = tuner.round;
         sl.u = u;
         sl.rgba = d_rgba;
         sl.bgra = d_bgra;
@@ -1209,6 +1281,8 @@ struct gs_renderer {
             st.ms_tile_boundary = 0.0f;
             st.ms_render = span(5, 7);
         }
+        // the blend tuner's sample: the blend's own span where the passes are timed, the frame's otherwise
+        tuner.sample(sl.timed ? st.ms_render : st.ms_total, sl.lockstep, sl.tune_round);
         st.retries = retries;
         last = st;
         have_frame = true;
@@ -1605,6 +1679,26 @@ int gs_set_blend_contraction(gs_renderer* r, int enabled) {
         r->drain();
         r->contract = enabled != 0;
     });
+}
+
+int gs_set_blend_lockstep(gs_renderer* r, int mode) {
+    return guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "null argument");
+        if (mode < -1 || mode > 1) throw Error(GS_ERR_INVALID, "blend lockstep: -1 automatic, 0 off, 1 on");
+        r->drain();
+        r->tuner.forced = mode;
+        if (mode < 0) r->tuner.restart();
+    });
+}
+
+int gs_get_blend_lockstep(gs_renderer* r, int* settled) {
+    int now = 0;
+    const int rc = guarded([&] {
+        if (!r) throw Error(GS_ERR_INVALID, "null argument");
+        now = r->tuner.current() ? 1 : 0;
+        if (settled) *settled = (r->tuner.forced >= 0 || r->tuner.phase == 2) ? 1 : 0;
+    });
+    return rc != 0 ? rc : now;
 }
 
 int gs_set_graph_mode(gs_renderer* r, int enabled) {

@@ -78,6 +78,8 @@ struct Counters {
     // written BY the guarded blend (the host copy, published when the blend starts, does not hold them; gs_get_stats reads the device words):
     uint32_t blend_resolved;  // break decisions (render.comp:83) inside the guard's window, resolved by replaying the pixel exactly
     uint32_t blend_redo;      // quadrants (8 x 8 px) abandoned and re-rendered whole with the reference's arithmetic
+    // the work queue of k_bin_queue (level 4 in one launch): items handed out so far (bins first, then depth slabs); bins beyond a slab planned so far
+    uint32_t q_head, q_bins_done;
 };
 // What changes from one frame to the next.  Normally these travel as kernel arguments; when a frame is replayed
 // as a captured HIP graph (gs_set_graph_mode) they are read from this block in device memory instead, which the
@@ -95,7 +97,7 @@ constexpr int kBinSortLevels = 5;
 constexpr int kBinSlabLevel = 4;
 constexpr uint32_t kBinSortLimit[kBinSortLevels] = {4096, 8192, 12288, 16384, 65535};
 constexpr int kBinSortMax = 16384;
-constexpr uint32_t kSlabDescBytes = 288, kSlabCapacity = 8192, kSlabWorkGroups = 512;
+constexpr uint32_t kSlabDescBytes = 288, kSlabCapacity = 8192, kSlabWorkGroups = 512, kQueueWorkGroups = 256;
 
 void launch_cov3d(const float* blob, float* cov3d, uint32_t n, uint32_t stride, hipStream_t s);
 // cut[i] = the most negative power <= 0 with !(min(0.99, opacity[i] * expf(power)) < 1/255)  (render.comp:77-78; +inf: none,
@@ -158,6 +160,8 @@ struct BinLaunch {
     uint32_t capacity;
     void* slabs;                // [slab_capacity] 288-byte depth-slab descriptors (level 4)
     uint32_t slab_capacity;
+    uint32_t slab_epoch;        // != 0: level 4 as ONE launch (k_bin_queue); a value no earlier launch on these descriptors carried
+                                // (a descriptor is ready when it holds this launch's epoch).  0: k_bin_slabs + k_slab_work
     uint32_t tiles_x, tiles_y, bins_x, bins_y;
     int bin_shift;              // log2 S
     int grid_shift;             // 4 or 5: padded bin id = by << grid_shift | bx
@@ -187,6 +191,8 @@ void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint
                                   of render.comp:82 (break decisions near the cut taken from mode 2's arithmetic; needs every
                                   opacity <= 1: the caller passes 2 for a scene that holds a larger one) */,
                   bool contract /* the three FMA contractions GLSL permits in render.comp:66,87, or (default) none */,
-                  const FrameParams* fp, hipStream_t s);
+                  const FrameParams* fp,
+                  bool lockstep /* the four waves of a tile take every chunk of its list together (s_barrier): gs_blend.hip */,
+                  hipStream_t s);
 
 }  // namespace gs

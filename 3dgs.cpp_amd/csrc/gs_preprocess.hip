@@ -394,6 +394,8 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
         pu.counters->slabs = 0;
         pu.counters->blend_resolved = 0;
         pu.counters->blend_redo = 0;
+        pu.counters->q_head = 0;
+        pu.counters->q_bins_done = 0;
     }
     preprocess_one(sv, u, av, i, i < sv.n, s_stage[threadIdx.x / WAVE]);
 }

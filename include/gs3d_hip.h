@@ -239,6 +239,16 @@ int gs_set_blend_contraction(gs_renderer* r, int enabled);
  * parameter block refreshed by one copy ahead of the launch).  Per-pass spans are not recorded in this mode
  * (ms_total still is).  Default off: it lowers the host's cost per frame, not the GPU's.  GS_GRAPH=1 sets the initial mode. */
 int gs_set_graph_mode(gs_renderer* r, int enabled);
+/* The blend's LOCKSTEP: the four waves of a 16 x 16 tile take every 64-entry chunk of its list together (one workgroup barrier per
+ * chunk), so that their gathers of the same splat records meet in the CU's L1.  It changes no pixel (the frames are bit-identical
+ * either way), only where the time goes: +25 % of the blend on trained-like scenes (long lists of which an 8 x 8 quadrant keeps one
+ * entry in seven: the kernel is bound by its L1 misses), -9 % on scenes whose blend is bound by the pair loop.  mode -1 (default):
+ * the renderer measures both over a few frames -- the blend's own span -- keeps the faster and looks again every 4096 frames or
+ * when the frame's size changes; 0 / 1: pinned off / on (also GS_BLEND_LOCKSTEP=0 / 1 at renderer creation). */
+int gs_set_blend_lockstep(gs_renderer* r, int mode);
+/* The setting the next frame will run with (0 / 1; negative: error); *settled (nullable) = 1 once the measurement has decided
+ * (or the mode is pinned). */
+int gs_get_blend_lockstep(gs_renderer* r, int* settled);
 /* Sums of the per-pass spans over all frames retired since the last reset (ms fields are sums,
  * counts are those of the last frame); *frames = number of frames summed.  Synchronizes. */
 int gs_get_timing_totals(gs_renderer* r, gs_frame_stats* sum, uint64_t* frames, int reset);

@@ -91,3 +91,39 @@ def test_blend_modes_against_the_reference_text(pkg, oracle, gpu, case):
         assert report[(0, True)][0] > 1e-4  # the regime the default exists for: the contracted reading is off by > 1e-4 here
     rend.close()
     scene.close()
+
+
+def test_blend_lockstep_changes_no_pixel_and_the_tuner_settles(pkg, gpu):
+    """gs_set_blend_lockstep: the tile's four waves taking every chunk together (a barrier per chunk) is a scheduling choice -- the frames must be
+    bit-identical pinned off, pinned on and while the renderer measures; the measurement must come to a decision within a few dozen frames."""
+    import ctypes
+    rec = pkg.synth.synth_records(60_000, seed=4, kind="T")
+    scene = pkg.Scene.from_records(rec, device=0)
+    w, h = 640, 360
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    images = {}
+    for mode in (0, 1):
+        for exp_mode in (3, 2):
+            rend = pkg.Renderer(scene)
+            rend.set_exp_mode(exp_mode)
+            rend.set_blend_lockstep(mode)
+            assert rend.blend_lockstep() == (bool(mode), True)
+            images[(mode, exp_mode)] = rend.render_host(u)[0]
+            rend.close()
+    for exp_mode in (3, 2):
+        assert np.array_equal(images[(0, exp_mode)].view(np.uint32), images[(1, exp_mode)].view(np.uint32)), exp_mode
+    rend = pkg.Renderer(scene)  # automatic: every frame on the way to the decision is the same frame
+    rend.set_exp_mode(3)
+    rend.set_blend_lockstep(-1)
+    rend.set_frames_in_flight(3)
+    assert rend.blend_lockstep()[1] is False
+    seen = set()
+    for k in range(60):
+        img = rend.render_host(u)[0]
+        assert np.array_equal(img.view(np.uint32), images[(0, 3)].view(np.uint32)), k
+        seen.add(rend.blend_lockstep()[0])
+        if rend.blend_lockstep()[1]:
+            break
+    assert rend.blend_lockstep()[1] is True and seen == {False, True}  # both settings were tried, one was chosen
+    rend.close()
+    scene.close()

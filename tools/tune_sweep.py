@@ -94,7 +94,8 @@ def main():
                 np.save(args.ref_image, img)
         same = bool(np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)))
         st = rend.stats()
-        print(f"fif {fif}  fps {np.median(fps):8.1f}  (min {min(fps):8.1f} max {max(fps):8.1f})  bit-equal {same} "
+        ls = rend.blend_lockstep() if hasattr(rend, "blend_lockstep") and hasattr(pkg.binding.lib(), "gs_get_blend_lockstep") else (None, None)
+        print(f"fif {fif}  fps {np.median(fps):8.1f}  (min {min(fps):8.1f} max {max(fps):8.1f})  bit-equal {same} lockstep {ls[0]}/{'settled' if ls[1] else 'measuring'} "
               f"V {st.num_visible} E1 {st.num_bin_entries} D {st.num_instances} lvl {st.sort_level} path {st.sort_path} bin {st.bin_tiles} maxbin {st.max_bin_entries}  spans us [pre l1cnt l1scat bin blend total] {spans}",
               flush=True)
         if args.json_out:
