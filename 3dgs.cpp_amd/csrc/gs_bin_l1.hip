@@ -391,7 +391,7 @@ static L1Args l1_args(const BinLaunch& b) {
     a.bin_count = b.bin_count;
     a.cand = b.cand;
     a.counters = b.counters;
-    a.capacity = b.capacity;
+    a.capacity = b.cand_capacity;  // (level 1 only ever writes candidates)
     // level-1 blocks: over the N items, or over the slots of the dense lists
     a.nblk = b.vis ? kVisRegions * (b.vis_region_slots / kL1Items) : bin_level1_blocks(b.n_bound);
     return a;

@@ -41,7 +41,8 @@ struct BuildArgs {
     uint32_t* ranges;      // [T][2]
     uint32_t* sorted_gid;  // [capacity]
     Counters* counters;
-    uint32_t capacity;
+    uint32_t capacity;       // tile instances the lists hold
+    uint32_t cand_capacity;  // level-1 candidates the candidate buffer holds
     SlabDesc* slabs;       // k_bin_slabs -> k_slab_work (level 4)
     uint32_t slab_capacity;
     uint32_t epoch;        // k_bin_queue: see BinLaunch::slab_epoch
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot_mine);   // block-uniform: keep them scalar
         off = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot_before);
     }
-    if ((uint64_t)off + c > a.capacity) c = 0;  // candidate overflow (flagged by k_l1_scatter): the frame is re-run
+    if ((uint64_t)off + c > a.cand_capacity) c = 0;  // candidate overflow (flagged by k_l1_scatter): the frame is re-run
     if (SORT && c > (uint32_t)MAXC) {
         if (tid == 0) atomicOr(&a.counters->overflow, 2u);
         c = 0;
@@ -478,7 +479,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
         // load wrapped in a readfirstlane loop with a full s_waitcnt, i.e. serialised
         c_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)tm);
         off = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
-        if ((uint64_t)off + c_total > a.capacity) c_total = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
+        if ((uint64_t)off + c_total > a.cand_capacity) c_total = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
         if (c_total > kMaxInBin) {
             if (tid == 0) atomicOr(&a.counters->overflow, 2u);
             c_total = 0;
@@ -1438,6 +1439,7 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
     a.sorted_gid = b.sorted_gid;
     a.counters = b.counters;
     a.capacity = b.capacity;
+    a.cand_capacity = b.cand_capacity;
     a.slabs = reinterpret_cast<SlabDesc*>(b.slabs);
     a.slab_capacity = b.slab_capacity;
     a.epoch = b.slab_epoch;

@@ -554,7 +554,7 @@ struct FrameBuffers {
     DevBuf<uint32_t> block_hist, digit_total;
     // two-level binning
     DevBuf<uint32_t> l1_hist, bin_count;  // [padded bins][level-1 blocks], [1024]
-    DevBuf<uint32_t> cand;                // [3 x capacity] bin-major candidates: 12-byte records {depth bits, id, box} on the bin-local path, plain ids otherwise
+    DevBuf<uint32_t> cand;                // [3 x cand_capacity] bin-major candidates: 12-byte records {depth bits, id, box} on the bin-local path, plain ids otherwise
     DevBuf<uint32_t> sorted;              // [capacity + 4] per-tile lists, bin-major
     DevBuf<uint32_t> ranges;              // [T][2]
     DevBuf<uint8_t> slabs;                // depth-slab descriptors (level 4; allocated on first use)
@@ -565,12 +565,12 @@ struct FrameBuffers {
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey {
         int level = -1, hw_exp = 0, contract = 1, bin_shift = -1;
-        uint32_t width = 0, height = 0, capacity = 0;
+        uint32_t width = 0, height = 0, capacity = 0, cand_capacity = 0;
         const void *tile_order = nullptr, *ranges = nullptr, *sh16 = nullptr;
         bool lockstep = false;
         bool operator==(const GraphKey& o) const {
             return lockstep == o.lockstep && level == o.level && hw_exp == o.hw_exp && contract == o.contract && bin_shift == o.bin_shift && width == o.width && height == o.height &&
-                   capacity == o.capacity && tile_order == o.tile_order && ranges == o.ranges && sh16 == o.sh16;
+                   capacity == o.capacity && cand_capacity == o.cand_capacity && tile_order == o.tile_order && ranges == o.ranges && sh16 == o.sh16;
         }
     } graph_key;
     void drop_graph() {
@@ -581,7 +581,7 @@ struct FrameBuffers {
     size_t n = 0;
     bool ready = false;
 
-    void init(size_t n_, uint32_t capacity, const std::vector<uint32_t>& mask_prep, const std::vector<uint32_t>& mask_blend, bool dense_lists) {
+    void init(size_t n_, uint32_t capacity, uint32_t cand_capacity, const std::vector<uint32_t>& mask_prep, const std::vector<uint32_t>& mask_blend, bool dense_lists) {
         n = n_;
         if (!mask_prep.empty() && !mask_blend.empty()) {
             HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, static_cast<uint32_t>(mask_prep.size()), mask_prep.data()));
@@ -602,6 +602,7 @@ struct FrameBuffers {
         counters.alloc(1);
         params.alloc(1);
         set_capacity(capacity);
+        set_cand_capacity(cand_capacity);
         ready = true;
     }
     void ensure_dense_lists() {  // the dense lists of visible Gaussians: only scenes of >= dense_min Gaussians ever use them (16 B x N)
@@ -619,14 +620,17 @@ struct FrameBuffers {
         block_hist.alloc(256 * static_cast<size_t>(gs::kSortMaxBlocks));
         digit_total.alloc(256);
     }
-    void set_capacity(uint32_t cap) {
+    void set_capacity(uint32_t cap) {  // D: the per-tile lists
         drop_graph();  // the captured launches hold the old buffers
-        cand.alloc(3 * static_cast<size_t>(cap));
-        // a frame whose candidates overflow the capacity leaves a gap of unwritten entries that k_bin_build still
-        // gathers through before the frame is re-run: the gap must hold valid Gaussian ids (0), never whatever
-        // hipMalloc handed back
-        HIP_CHECK(hipMemset(cand.p, 0, 3 * static_cast<size_t>(cap) * sizeof(uint32_t)));
         sorted.alloc(static_cast<size_t>(cap) + 4);  // + 4: a 16-byte list store that starts inside the capacity may end past it
+    }
+    // E1: the level-1 candidates, sized on their own (round 5; they used to share the instance capacity: 3 words x 8 N, six times what
+    // config B's 0.74 M records need).  A frame whose candidates overflow leaves a gap of unwritten entries that k_bin_build still
+    // gathers through before the frame is re-run: the gap must hold valid Gaussian ids (0), never whatever hipMalloc handed back.
+    void set_cand_capacity(uint32_t ccap) {
+        drop_graph();
+        cand.alloc(3 * static_cast<size_t>(ccap));
+        HIP_CHECK(hipMemset(cand.p, 0, 3 * static_cast<size_t>(ccap) * sizeof(uint32_t)));
     }
     void sync() const {
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -667,7 +671,8 @@ struct gs_renderer {
 
     FrameBuffers sets[kMaxInFlight];
     int num_sets = 1;
-    uint32_t capacity = 0;
+    uint32_t capacity = 0;       // tile instances (D) the list buffers hold
+    uint32_t cand_capacity = 0;  // level-1 candidates (E1) the candidate buffers hold
     FrameBuffers* last_set = nullptr;  // buffers of the most recently enqueued frame (stage taps)
 
     // frames in flight: a ring of descriptors, all enqueued on `stream` (so device buffers are
@@ -810,6 +815,11 @@ struct gs_renderer {
         for (auto& fb : sets)
             if (fb.ready) fb.set_capacity(cap);
     }
+    void set_cand_capacity(uint32_t ccap) {
+        cand_capacity = ccap;
+        for (auto& fb : sets)
+            if (fb.ready) fb.set_cand_capacity(ccap);
+    }
 
     void init() {
         if (const char* e = std::getenv("GS_BLEND_LOCKSTEP")) tuner.forced = std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0);
@@ -828,8 +838,13 @@ struct gs_renderer {
         // test knob: start small so that the overflow / grow / re-run machinery is exercised by small scenes
         if (const char* e = std::getenv("GS_INITIAL_CAPACITY")) want = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
         capacity = static_cast<uint32_t>(std::min<uint64_t>(want, kMaxInstances));
+        // candidates: E1 <= D always; ~1.5 per visible Gaussian with bins of 8 x 8 tiles, ~2 with 4 x 4 (config B 0.74 M, E 4.6 M, T 5.3 M)
+        uint64_t want_cand = std::max<uint64_t>(1u << 18, 2 * static_cast<uint64_t>(scene->n));
+        if (const char* e = std::getenv("GS_INITIAL_CAND_CAPACITY")) want_cand = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
+        else if (std::getenv("GS_INITIAL_CAPACITY")) want_cand = std::min<uint64_t>(want_cand, want);  // (the tests' small start applies to both)
+        cand_capacity = static_cast<uint32_t>(std::min<uint64_t>(want_cand, capacity));
         parse_cu_masks();
-        sets[0].init(scene->n, capacity, mask_prep, mask_blend, scene->n >= dense_min);
+        sets[0].init(scene->n, capacity, cand_capacity, mask_prep, mask_blend, scene->n >= dense_min);
     }
 
     // Experiment: GS_CU_MASK_PREP / GS_CU_MASK_BLEND = hex strings, most significant CU first,
@@ -851,7 +866,7 @@ struct gs_renderer {
 
     void set_num_sets(int k) {
         for (int i = 0; i < k; ++i)
-            if (!sets[i].ready) sets[i].init(scene->n, capacity, mask_prep, mask_blend, scene->n >= dense_min);
+            if (!sets[i].ready) sets[i].init(scene->n, capacity, cand_capacity, mask_prep, mask_blend, scene->n >= dense_min);
         num_sets = k;
     }
 
@@ -1039,6 +1054,7 @@ struct gs_renderer {
                 b.sorted_gid = fb.sorted.p;
                 b.counters = cnt;
                 b.capacity = capacity;
+                b.cand_capacity = cand_capacity;
                 b.slabs = fb.slabs.p;
                 b.slab_capacity = fb.slabs.p ? gs::kSlabCapacity : 0u;
                 // level 4 as one launch over a queue of bins and slabs -- not in a captured frame (a replay repeats its arguments,
@@ -1092,6 +1108,7 @@ struct gs_renderer {
             key.width = u.width;
             key.height = u.height;
             key.capacity = capacity;
+            key.cand_capacity = cand_capacity;
             key.tile_order = tile_order.p;
             key.ranges = fb.ranges.p;
             key.sh16 = sv.sh16;
@@ -1157,7 +1174,7 @@ struct gs_renderer {
                 uint8_t* bgra;
             };
             std::vector<Redo> redo;
-            uint64_t need = 0;
+            uint64_t need = 0, need_cand = 0;
             uint32_t fullest = 0;
             bool grow = false, bin_too_big = false;
             for (int k = 0; k < pending; ++k) {
@@ -1165,8 +1182,10 @@ struct gs_renderer {
                 redo.push_back({q.u, q.rgba, q.bgra});
                 if (q.h_counters->overflow & 1u) {
                     grow = true;
-                    // D instances and E1 level-1 candidates share the capacity
-                    need = std::max<uint64_t>(need, std::max<uint64_t>(q.h_counters->instances, q.h_counters->bin_entries));
+                    // which of the two ran over: the level-1 candidates (E1: the frame's instance count then means nothing -- its
+                    // bins were skipped) or the per-tile lists (D)
+                    if (q.h_counters->bin_entries > cand_capacity) need_cand = std::max<uint64_t>(need_cand, q.h_counters->bin_entries);
+                    else need = std::max<uint64_t>(need, q.h_counters->instances);
                 }
                 // (a frame that ran with another level or bin size than the renderer's current ones says nothing about those)
                 const uint32_t qtx = (q.u.width + gs::kTile - 1) / gs::kTile, qty = (q.u.height + gs::kTile - 1) / gs::kTile;
@@ -1183,7 +1202,7 @@ struct gs_renderer {
                     std::fprintf(stderr, " [lvl %d bin 2^%d ovf %u max_bin %u E1 %u D %u slabs %u]", q.level, q.bin_shift, q.h_counters->overflow,
                                  q.h_counters->max_bin, q.h_counters->bin_entries, q.h_counters->instances, q.h_counters->slabs);
                 }
-                std::fprintf(stderr, " capacity %u\n", capacity);
+                std::fprintf(stderr, " capacity %u candidates %u\n", capacity, cand_capacity);
             }
             // the queued frames are dropped from the ring first: whatever is thrown below, the renderer stays usable
             frames_enqueued -= pending;
@@ -1214,8 +1233,13 @@ struct gs_renderer {
             // runaway guard: one frame may need a path fall-back and a few grow steps (each grow is sized from the counts
             // the overflowing frame reported, so it converges at once unless the chunk table and the lists take turns)
             if (++redo_chain > 8) throw Error(GS_ERR_OVERFLOW, "instance buffers overflowed repeatedly");
-            if (grow) {
-                need = need + need / 2 + 4096;  // 1.5x head-room: a moving camera should not re-grow every few frames
+            if (grow && need_cand > cand_capacity) {
+                need_cand = need_cand + need_cand / 2 + 4096;  // 1.5x head-room: a moving camera should not re-grow every few frames
+                if (need_cand > kMaxInstances) throw Error(GS_ERR_OVERFLOW, "more than 2^30 level-1 candidates");
+                set_cand_capacity(static_cast<uint32_t>(need_cand));
+            }
+            if (grow && need > capacity) {
+                need = need + need / 2 + 4096;
                 if (need > kMaxInstances) throw Error(GS_ERR_OVERFLOW, "more than 2^30 tile instances");
                 set_capacity(static_cast<uint32_t>(need));
             }

@@ -153,11 +153,12 @@ struct BinLaunch {
     uint32_t vis_region_slots;
     uint32_t* hist;             // [padded bins + 1][bin_level1_columns(n_bound)] (the last row: visible items per block)
     uint32_t* bin_count;        // [1024]
-    uint32_t* cand;             // [capacity]
+    uint32_t* cand;             // [cand_capacity] records (3 words each) or ids
     uint32_t* ranges;           // [T][2]
     uint32_t* sorted_gid;       // [capacity (+4)]
     Counters* counters;
-    uint32_t capacity;
+    uint32_t capacity;          // tile instances the lists hold
+    uint32_t cand_capacity;     // level-1 candidates the candidate buffer holds
     void* slabs;                // [slab_capacity] 288-byte depth-slab descriptors (level 4)
     uint32_t slab_capacity;
     uint32_t slab_epoch;        // != 0: level 4 as ONE launch (k_bin_queue); a value no earlier launch on these descriptors carried
