@@ -78,21 +78,6 @@ __device__ __forceinline__ float min_q_rect(float c00, float c01, float c11, flo
     return in_x ? (in_y ? 0.0f : qh) : (in_y ? qv : fminf(qv, qh));
 }
 
-#ifdef GS_BLEND_TIMING
-// debug instrumentation (separate build, never the shipped library; tools/blend_timing.py): where a wave's cycles go, per chunk --
-// [9] loop top .. the chunk's keep-ballot (the wait for the prefetched records + the classification), [10] ballot .. end of the pair
-// loop (staging + pairs), [11] chunks that had a kept entry
-__device__ unsigned long long g_blend_stats[12];
-#define TIME_NOW() __builtin_readcyclecounter()
-#define TIME_ADD(i, v) do { t_acc[(i) - 9] += (unsigned long long)(v); } while (0)  /* per wave; one atomic each when the walk ends */
-#define TIME_DECL() unsigned long long t_acc[3] = {0, 0, 0}
-#define TIME_FLUSH() do { if (lane == 0) { atomicAdd(&g_blend_stats[9], t_acc[0]); atomicAdd(&g_blend_stats[10], t_acc[1]); atomicAdd(&g_blend_stats[11], t_acc[2]); } } while (0)
-#else
-#define TIME_DECL() do { } while (0)
-#define TIME_FLUSH() do { } while (0)
-#define TIME_NOW() 0ull
-#define TIME_ADD(i, v) do { } while (0)
-#endif
 #ifdef GS_BLEND_STATS
 // debug instrumentation (separate build, never the shipped library)
 __device__ unsigned long long g_blend_stats[12];
@@ -218,10 +203,9 @@ __device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist
 // replaces (every product and sum of render.comp:66 rounded on its own, v_exp_f32, fl(o e), min, 1 - alpha, T (1 - alpha), the
 // fused accumulate of the guarded mode): the images of the two loops are bit-identical (tools/ab_image_check.py).
 // The loop returns to C++ (event = 1) only where the guard needs it: a lane of m2 inside the guard's COARSE window around 1e-4 (the
-// slice test, one instruction on every pair, sends 3 % of the pairs of config B and ~15 % of T(6e6)'s -- every pixel of a dense scene
-// crosses 1e-4, in steps of a per cent -- to the two compares of the coarse window, still inside the loop; a third of those leave it);
-// the pending pair is then finished by the caller (own window, resolve_break, accumulate) and the loop re-entered.  Leaving costs
-// ~700 cycles (the slab is re-read on both sides): with every slice hit leaving, T(6e6)'s blend took 505 us against the compiler's 415.
+// slice test, one instruction on every pair, sends ~3 % of the pairs to the two compares of the coarse window, still inside the loop;
+// a third of those leave it); the pending pair is then finished by the caller (own window, resolve_break, accumulate) and the loop
+// re-entered (leaving costs a few hundred cycles: the slab is re-read on both sides).
 // Loaded records live in v[54:63] (a 128-bit operand's components cannot be named in inline asm): clobbered, the allocator
 // keeps out.  Hazards inside the string: v_exp_f32 -> its consumer (trans op, 1 state: the s_nop); none of the others apply
 // (no DPP / readlane / VMEM here; SALU and branch reads of VALU-written VCC / EXEC / SGPRs are interlocked).
@@ -232,9 +216,6 @@ __device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist
 #ifndef GS_BLEND_TAIL_CSELECT
 #define GS_BLEND_TAIL_CSELECT 1  // 1: "the last pixel died" folds into the count (s_cselect: the loop ends at its own test) instead of a branch
                                  // of its own; with the line above 168 -> 166 us (alone: neutral)
-#endif
-#ifndef GS_BLEND_ASM_FULLEXEC
-#define GS_BLEND_ASM_FULLEXEC 0  // 1 (experiment): loads and `power` under the full exec, alive applied after the compares
 #endif
 struct PairLoopEvent {
     uint64_t m2, mk, sl;   // lanes that evaluated exp; of those: T (1 - alpha) < 1e-4 with the fast exp; inside the slice
@@ -253,9 +234,7 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
     uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
-#if !GS_BLEND_ASM_FULLEXEC
         "s_mov_b64 exec, %[alive]\n"
-#endif
         ".Lgs_pair_%=:\n\t"
         "ds_read_b128 v[54:57], %[addr]\n\t"
         "ds_read_b128 v[58:61], %[addr] offset:1024\n\t"
@@ -274,9 +253,6 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
         "v_add_f32 v54, v55, v54\n\t"             // power = s + c01' dx dy            (render.comp:66)
         "v_cmpx_ge_f32 vcc, 0, v54\n\t"           // power <= 0 (false for NaN)        (render.comp:68)
         "v_cmpx_nlt_f32 vcc, v54, v63\n\t"        // !(power < alpha cut)              (render.comp:78, decided on power)
-#if GS_BLEND_ASM_FULLEXEC
-        "s_and_b64 exec, exec, %[alive]\n\t"
-#endif
 #if GS_BLEND_EXECZ_BRANCH
         "s_cbranch_execz .Lgs_skip_%=\n\t"
 #endif
@@ -303,11 +279,7 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
         "s_cbranch_scc0 .Lgs_done_%=\n"            // every pixel of the quadrant has saturated
 #endif
         ".Lgs_skip_%=:\n\t"
-#if GS_BLEND_ASM_FULLEXEC
-        "s_mov_b64 exec, %[sv]\n\t"
-#else
         "s_mov_b64 exec, %[alive]\n\t"
-#endif
         "s_add_u32 %[rem], %[rem], -1\n\t"         // carry = there was another pair
         "s_cbranch_scc1 .Lgs_pair_%=\n"
         ".Lgs_done_%=:\n\t"
@@ -331,76 +303,6 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
     return event;
 }
 
-// The same loop with NO vector-written exec (GS_BLEND_ASM_LOOP == 2): where few waves of a SIMD are in their pair loops at a time -- a
-// scene whose records come from HBM (T(6e6): 183 MB of records, a wave waits for every chunk's gather) -- what counts is one wave's
-// latency per pair, and v_cmpx costs it twice the depth of the vector pipeline (the next vector instruction needs the new exec).  Here
-// the two tests are plain v_cmp into scalar masks, the exp section runs on every ALIVE lane with alpha forced to 0 outside m2 (T * 1
-// and c + 0 r are exact; the accumulate still runs under exec = m2 & ~mk, so a NaN colour stays where the reference puts it), and
-// exec is only ever written by the scalar unit.  26 vector + 10 scalar instructions per pair.
-__device__ __forceinline__ uint32_t blend_pair_loop_lat(uint32_t& slab_addr, uint32_t& rem, uint64_t& alive, const float fx, const float fy, float& T,
-                                                        float& c0, float& c1, float& c2, PairLoopEvent& ev) {
-    uint32_t event;
-    uint64_t saved;
-    const float k1e4 = 0.0001f;
-    uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[alive]\n"
-        ".Lgs3_pair_%=:\n\t"
-        "ds_read_b128 v[54:57], %[addr]\n\t"
-        "ds_read_b128 v[58:61], %[addr] offset:1024\n\t"
-        "ds_read_b64 v[62:63], %[addr] offset:2048\n\t"
-        "v_add_u32 %[addr], 16, %[addr]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_sub_f32 v58, v58, %[fx]\n\t"
-        "v_sub_f32 v59, v59, %[fy]\n\t"
-        "v_mul_f32 v54, v54, v58\n\t"
-        "v_mul_f32 v56, v56, v59\n\t"
-        "v_mul_f32 v54, v58, v54\n\t"
-        "v_mul_f32 v56, v59, v56\n\t"
-        "v_mul_f32 v55, v55, v58\n\t"
-        "v_add_f32 v54, v54, v56\n\t"
-        "v_mul_f32 v55, v55, v59\n\t"
-        "v_add_f32 v54, v55, v54\n\t"             // power                              (render.comp:66)
-        "v_cmp_ge_f32 vcc, 0, v54\n\t"            // power <= 0                         (render.comp:68)
-        "v_cmp_nlt_f32 %[m2], v54, v63\n\t"       // !(power < alpha cut)               (render.comp:78)
-        "v_mul_f32 v56, 0x3fb8aa3b, v54\n\t"
-        "v_exp_f32 v56, v56\n\t"
-        "s_and_b64 %[m2], %[m2], vcc\n\t"         // m2 (inside alive: the compares ran under exec = alive)
-        "v_mul_f32 v56, v57, v56\n\t"
-        "v_min_f32 v56, 0x3f7d70a4, v56\n\t"
-        "v_cndmask_b32 v56, 0, v56, %[m2]\n\t"    // alpha = 0 outside m2: T and the colour stay as they are, exactly
-        "v_sub_f32 v55, 1.0, v56\n\t"
-        "v_mul_f32 %[w], v56, %[T]\n\t"
-        "v_mul_f32 %[T], %[T], v55\n\t"
-        "v_cmp_gt_f32 vcc, %[k1e4], %[T]\n\t"
-        "v_cmp_eq_u32_sdwa %[sl], %[T], %[slice] src0_sel:WORD_1 src1_sel:DWORD\n\t"
-        "s_and_b64 %[mk], vcc, %[m2]\n\t"         // (a lane outside m2 may carry a T that a replay let pass just below 1e-4)
-        "s_and_b64 %[sl], %[sl], %[m2]\n\t"
-        "s_cbranch_scc1 .Lgs3_event_%=\n\t"
-        "s_andn2_b64 exec, %[m2], %[mk]\n\t"
-        "v_fmac_f32 %[c0], v60, %[w]\n\t"
-        "v_fmac_f32 %[c1], v61, %[w]\n\t"
-        "v_fmac_f32 %[c2], v62, %[w]\n\t"
-        "s_andn2_b64 %[alive], %[alive], %[mk]\n\t"
-        "s_cselect_b32 %[rem], %[rem], 0\n\t"
-        "s_mov_b64 exec, %[alive]\n\t"
-        "s_add_u32 %[rem], %[rem], -1\n\t"
-        "s_cbranch_scc1 .Lgs3_pair_%=\n\t"
-        "s_mov_b32 %[ev], 0\n\t"
-        "s_branch .Lgs3_exit_%=\n"
-        ".Lgs3_event_%=:\n\t"
-        "s_mov_b32 %[ev], 1\n"
-        ".Lgs3_exit_%=:\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [T] "+v"(T), [addr] "+v"(slab_addr), [alive] "+s"(alive), [rem] "+s"(left),
-          [ev] "=&s"(event), [mk] "=&s"(ev.mk), [m2] "=&s"(ev.m2), [sl] "=&s"(ev.sl), [sv] "=&s"(saved), [w] "=&v"(ev.w)
-        : [fx] "v"(fx), [fy] "v"(fy), [k1e4] "s"(k1e4), [slice] "s"(kGuardSlice)
-        : "vcc", "scc", "memory", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-    rem = left;
-    return event;
-}
-
 // One pass of a wave over its tile's list: returns false if the quadrant has to be re-rendered exactly (GUARD only; c0..c2
 // are then meaningless).  slab: this wave's three planes of 64 float4 {c00' c01' c11' o} {u v r g} {b, cut, -, -} --
 // plane-major keeps the staging ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets
@@ -418,7 +320,6 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
 #else
     constexpr bool kAsmLoop = GUARD && EXP == 1 && !CONTRACT && GS_BLEND_ASM_LOOP != 0;
 #endif
-    TIME_DECL();
     float T = 1.0f;
     c0 = c1 = c2 = 0.0f;
     uint32_t npairs = 0;                       // GUARD: (entry, wave) pairs evaluated so far (bounds every lane's step count)
@@ -448,7 +349,6 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
         // bound by the pair loop (S scenes) the waves wait for the slowest of four at every chunk and lose 9 %.  The renderer
         // measures both and keeps the faster (gs_capi.cpp: BlendTuner); the frames are bit-identical.
         if (lockstep) __builtin_amdgcn_s_barrier();
-        const unsigned long long t_top = TIME_NOW();
         const BlendEntry cur = nxt;
         const uint32_t g_cur = g_nxt;  // GUARD: this chunk's Gaussian ids (for the wave's list of kept entries)
         const bool have = base + lane < range.y;
@@ -476,8 +376,6 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
             keep = !(mq > __builtin_fmaf(mag, 9.6e-7f, -cut));  // NaN -> keep
         }
         uint64_t bm = __ballot(keep);
-        const unsigned long long t_cls = TIME_NOW();
-        TIME_ADD(9, t_cls - t_top);
         STAT_ADD(0, 1);
         STAT_ADD(6, __popcll(__ballot(have)));
         STAT_ADD(1, __popcll(bm));
@@ -510,8 +408,7 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
             uint32_t rem = n_kept - 1u;
             uint32_t slab_addr = (uint32_t)(uintptr_t)&slab[0][0];  // (the low half of a flat LDS pointer is the LDS offset)
             PairLoopEvent ev;
-            while ((GS_BLEND_ASM_LOOP == 2 ? blend_pair_loop_lat(slab_addr, rem, alive, fx, fy, T, c0, c1, c2, ev)
-                                             : blend_pair_loop(slab_addr, rem, alive, fx, fy, T, c0, c1, c2, ev)) != 0) {
+            while (blend_pair_loop(slab_addr, rem, alive, fx, fy, T, c0, c1, c2, ev) != 0) {
                 // a lane of ev.m2 has its T (1 - alpha) -- now in T -- inside the slice around 1e-4: the pending pair is finished here
                 const float test_T = T;
                 uint64_t mk = ev.mk;
@@ -571,22 +468,9 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
         // conic pre-scaled once per entry: (-c00/2, -c01, -c11/2).  Scaling by a power of two commutes with every
         // rounding below, so power is bit-identical to render.comp:66 evaluated as written while the per-pixel body
         // loses the -0.5 multiply
-#ifdef GS_BLEND_COMPACT_C  // experiment: the compiler's loop over the COMPACTED slab (what the hand-written loop walks)
-        if (keep) {
-            slab[0][rank] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
-            slab[1][rank] = cur.uv;
-            slab[2][rank] = make_float4(cur.bc.x, cut, 0.0f, 0.0f);
-        }
-        __builtin_amdgcn_wave_barrier();
-        {
-            const uint32_t nk = (uint32_t)__popcll(bm0);
-            bm = nk >= 64u ? ~0ull : ((1ull << nk) - 1ull);
-        }
-#else
         slab[0][lane] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
         slab[1][lane] = cur.uv;
         slab[2][lane] = make_float4(cur.bc.x, cut, 0.0f, 0.0f);
-#endif
 
         while (bm) {
             const int k = __ffsll((unsigned long long)bm) - 1;
@@ -661,11 +545,7 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                                     amb &= amb - 1;
                                     const float fxa = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fx), a));
                                     const float fya = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fy), a));
-#ifdef GS_BLEND_COMPACT_C
-                                    const uint32_t pos = kbase + (uint32_t)k;
-#else
                                     const uint32_t pos = kbase + (uint32_t)__popcll(bm0 & ((1ull << k) - 1ull));  // the tested entry in the list
-#endif
                                     // past the list's end, or one pixel too many: the quadrant is abandoned at the next chunk and
                                     // re-rendered exactly (necessary / cheaper)
                                     if (pos >= kGuardList || resolved >= kGuardMaxResolves) abandon = true;
@@ -744,8 +624,6 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
             }
         }
         }  // (the compiler's form of the pair loop)
-        TIME_ADD(10, TIME_NOW() - t_cls);
-        TIME_ADD(11, 1);
         if (alive == 0) break;
         if (GUARD) {  // chunk end: sum a/(1 - a) over the chunk's steps <= T_start / T_end - 1 (1e-5: v_rcp_f32's ULP)
             S += __builtin_fmaf(T_cs * 1.00001f, __builtin_amdgcn_rcpf(T), -1.0f);
@@ -753,7 +631,6 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
         }
     }
     STAT_ADD(7, (unsigned long long)__popcll(alive) * (range.y - range.x));  // pixels that never broke walk the whole list
-    TIME_FLUSH();
     return !abandon;
 }
 
@@ -942,7 +819,7 @@ extern "C" int gs_debug_expf_scan(int device, uint32_t first_bits, uint64_t coun
     return rc;
 }
 
-#if defined(GS_BLEND_STATS) || defined(GS_BLEND_TIMING)
+#ifdef GS_BLEND_STATS
 extern "C" int gs_debug_blend_stats(unsigned long long* out, int reset) {
     unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_stats), sizeof z) != hipSuccess) return -1;

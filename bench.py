@@ -275,6 +275,7 @@ def main():
     sums, frames = rend.timing_totals(reset=True)
     intervals = rend.frame_intervals(reset=True)  # completion-to-completion, GPU timestamps, this rank's K frames
     st = rend.stats()
+    lockstep = rend.blend_lockstep()  # what the renderer's own measurement chose for this workload (gs_set_blend_lockstep)
 
     # diagnostic only: the same frame with ONE frame in flight, so that per-pass spans are not stretched by
     # the other streams' kernels (the timed region above overlaps frames; its spans include that contention)
@@ -366,6 +367,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_name(n, w, h, world, args.scene, args.ply), "scene": "ply" if args.ply else args.scene,
                        "blend": BLEND_TEXT[mode], "blend_guard": guard,
+                       "blend_lockstep": {"on": bool(lockstep[0]), "settled": bool(lockstep[1]),
+                                          "what": "a tile's four waves take every chunk of its list together (their record gathers meet in L1); "
+                                                  "automatic: the renderer measures both settings and keeps the faster -- frames are bit-identical either way"},
                        "gaussians": int(st.num_gaussians), "visible": int(st.num_visible),
                        "instances": int(st.num_instances), "bin_entries": int(st.num_bin_entries), "tiles": T, "output": "bgra8" if args.bgra8_only else ("rgba32f" + ("+bgra8" if args.bgra8 else "")),
                        "frames_in_flight": args.frames_in_flight, "parallelism": f"pose-sharded x{world}",
@@ -491,7 +495,7 @@ def other_configs(pkg, torch, dev, device, args, budget_s):
             rend.set_exp_mode(MODES[mode][0])
             rend.set_blend_contraction(MODES[mode][1])
             rend.set_frames_in_flight(fif)
-            for i in range(max(10, frames // 4)):
+            for i in range(max(60, frames // 2)):  # warm: depth-order level settled, the blend's lockstep measured and chosen
                 rend.render(u, outs[i % fif].data_ptr(), 0)
             rend.synchronize()
             best = []
@@ -505,11 +509,14 @@ def other_configs(pkg, torch, dev, device, args, budget_s):
         fps = rate("default", 120)
         fps_exact = rate("exact", 120)
         rend.set_exp_mode(MODES["default"][0])
+        lockstep = rend.blend_lockstep()
         rend.set_frames_in_flight(1)
         rend.timing_totals(reset=True)
+        ts = time.perf_counter()
         for i in range(40):
             rend.render(u, outs[0].data_ptr(), 0)
         rend.synchronize()
+        serial_fps = 40 / (time.perf_counter() - ts)
         ssum, sframes = rend.timing_totals(reset=True)
         img_default = rend.render_host(u)[0]
         st = rend.stats()
@@ -518,6 +525,8 @@ def other_configs(pkg, torch, dev, device, args, budget_s):
         entry_ = {"workload": workload_name(n, w, h, 1, kind), "label": label, "frames_per_s": round(fps, 2), "frames_per_s_exact": round(fps_exact, 2),
                   "gaussians": int(st.num_gaussians), "visible": int(st.num_visible), "instances": int(st.num_instances),
                   "sort_level": int(st.sort_level), "bin_tiles": int(st.bin_tiles), "frames_in_flight": fif,
+                  "frames_per_s_one_in_flight": round(serial_fps, 2),
+                  "blend_lockstep": {"on": bool(lockstep[0]), "settled": bool(lockstep[1]), "what": "gs_set_blend_lockstep(-1): measured by the renderer"},
                   "passes_serial_ms": {k: round(getattr(ssum, "ms_" + k) / max(sframes, 1), 4)
                                        for k in ("preprocess", "prefix_sum", "preprocess_sort", "sort", "tile_boundary", "render", "total")},
                   "blend_guard": {"break_decisions_resolved_exactly": int(st.blend_resolved), "quadrants_rerendered_exactly": int(st.blend_redo)},

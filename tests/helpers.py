@@ -112,6 +112,9 @@ def assert_images_identical(img, ref_img, label=""):
     a, b = np.ascontiguousarray(img, np.float32).view(np.uint32), np.ascontiguousarray(ref_img, np.float32).view(np.uint32)
     if not np.array_equal(a, b) and HOST_LIBM_MISMATCHES:
         import pytest
+        # a foreign libm explains last-bit differences of exp(), nothing larger: wrong lists, a wrong blend or a permutation bug still FAIL here
+        d = float(np.abs(np.asarray(img, np.float64) - np.asarray(ref_img, np.float64)).max())
+        assert d <= 1e-5, f"{label}: images differ by {d:.3g} -- more than a different libm expf can explain"
         pytest.xfail(f"{label}: images differ, and this host's libm expf is not glibc's x86-64 FMA build ({HOST_LIBM_MISMATCHES} sampled "
                      "disagreements with the restated algorithm): the bit-identity claim is 'glibc expf (FMA build) + uncontracted render.comp'")
     if not np.array_equal(a, b):

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_images_identical, compare_stages, oracle_frame
+from helpers import assert_guarded_close, assert_images_identical, compare_stages, oracle_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -25,6 +25,10 @@ def _run(pkg, oracle, rec, w, h, camera=None):
     u = pkg.camera_uniforms(cam, w, h)
     assert u.tobytes() == u_ref.tobytes(), "Renderer::updateUniforms restatements disagree"
     img, bgra = rend.render_host(u, want_rgba=True, want_bgra=True)
+    # ... and the same frame in the library's DEFAULT blend (exp mode 3: the kernel that ships; the suite's renderers start in mode 2 for the
+    # bitwise comparisons, conftest.py): rounding noise from the checker, no flip budget.  (Leaves the renderer in mode 2; the stage taps
+    # of the callers read lists, which no blend mode touches.)
+    assert_guarded_close(rend, u, ref["image"], label=f"{len(rec)} Gaussians @ {w}x{h}, default blend")
     return scene, rend, u, ref, img, bgra
 
 

@@ -76,9 +76,30 @@ def test_viewer_keeps_frames_in_flight_when_nothing_is_dumped(pkg, gpu, tmp_path
         env = dict(os.environ, GS_FRAMES="300", GS_FRAMES_IN_FLIGHT=fif)
         env.pop("GS_DUMP_DIR", None)
         env.pop("GS_METRICS_CSV", None)
+        env.pop("GS_EXP_MODE", None)  # the library's own default blend (the suite's environment pins mode 2 for its bitwise comparisons)
         out = subprocess.run([exe, "--no-gui", "--width", "640", "--height", "360", ply], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
         assert "error" not in out.stderr.lower(), out.stderr
+
+
+def test_unchanged_reference_viewer_in_the_default_blend(pkg, oracle, gpu, tmp_path):
+    """The same viewer with nothing in its environment but the frame dump: lib3dgs_cpp in its real default (exp mode 3, the guarded v_exp_f32).
+    Its B8G8R8A8 frame may differ from the checker's by one unit in a channel where rounding noise (<= 1e-5) straddles an 8-bit boundary,
+    never by more."""
+    exe = os.path.join(PKG, "viewer_ref")
+    if not os.path.exists(exe):
+        pytest.skip("viewer_ref was not built (the reference tree was not mounted at build time)")
+    rec = pkg.synth.synth_records(6000, seed=12, kind="A")
+    ply = str(tmp_path / "scene.ply")
+    pkg.synth.write_ply(ply, rec)
+    w, h = 320, 208
+    env = dict(os.environ, GS_FRAMES="1", GS_DUMP_DIR=str(tmp_path))
+    env.pop("GS_EXP_MODE", None)
+    out = subprocess.run([exe, "--no-gui", "--width", str(w), "--height", str(h), ply], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = read_ppm(tmp_path / "frame_00000.ppm").astype(int)
+    ref = oracle_rgb8(oracle, oracle.activate_records(rec), oracle.default_camera(), w, h).astype(int)
+    assert np.abs(got - ref).max() <= 1 and np.mean(got != ref) < 1e-3
 
 
 def test_embedded_host_mode(pkg, oracle, gpu, tmp_path):
