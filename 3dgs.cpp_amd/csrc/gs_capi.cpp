@@ -712,46 +712,53 @@ struct gs_renderer {
     // The blend's LOCKSTEP (gs_blend.hip): the four waves of a tile take every chunk of its list together, so that their gathers of the
     // same records meet in L1.  Worth +25 % of the blend on trained-like scenes (L1-miss-bound: T(6e6) 505 -> 378 us; T(1e6) with three
     // frames in flight 2 675 -> 3 575 frames/s), -9 % on the S scenes (pair-loop-bound).  Nothing the renderer knows up front tells the
-    // two apart, so it MEASURES: a few frames each way (the blend's own span; the frames are bit-identical either way), keeps the
-    // faster, and looks again every 4096 frames or when the frame's shape changes.  GS_BLEND_LOCKSTEP=0 / 1 (or gs_set_blend_lockstep)
+    // two apart, so it MEASURES: sixteen frames each way (the rate at which frames complete; the frames are bit-identical either way), keeps
+    // lockstep where it wins by 3 %, and looks again every 4096 frames or when the frame's shape changes.  GS_BLEND_LOCKSTEP=0 / 1 (or gs_set_blend_lockstep)
     // pins it; the tuner then rests.
     struct BlendTuner {
-        static constexpr int kSkip = 2, kSamples = 6;   // per setting: frames ignored after the switch, frames measured
+        // What is compared is the rate at which frames COMPLETE under each setting -- the interval between the completions of consecutive
+        // frames (GPU timestamps), summed over a window -- not the blend's own span: with frames in flight a kernel's span says how much
+        // of the chip it was given, not what it cost (measured: on the S scenes the lockstepped blend's span is the shorter one with
+        // three frames in flight while the frame rate is 5 % lower).  Per setting: kSkip frames ignored after the switch (frames of the
+        // other setting are still in flight beside them), kSamples intervals summed.  Lockstep has to win by 3 %: off is the safe side
+        // (-9 % at worst against +25 %).
+        // The windows run OFF (8) - ON (16) - OFF (8): a drift of the clocks over the measurement -- a renderer's first frames run on a chip
+        // that is still coming up -- then weighs on both settings alike (measured: with a plain off-then-on order config B picked the
+        // lockstep it loses 5 % with, three times out of four).
+        static constexpr int kSkip = 6, kWindow = 8;
         static constexpr uint32_t kPeriod = 4096;       // settled frames between two looks
         int forced = -1;        // -1 automatic, 0 / 1 pinned
-        int phase = 0;          // 0: measuring lockstep off, 1: measuring on, 2: settled
+        int phase = 0;          // 0: off, 1: on (two windows), 2: off again, 3: settled
         bool choice = false;    // the settled setting
         uint32_t round = 1, seen = 0, settled_frames = 0;
         double sum[2] = {0, 0};
-        int count[2] = {0, 0};
-        bool current() const { return forced >= 0 ? forced != 0 : (phase == 2 ? choice : phase == 1); }
+        int count = 0;
+        bool measuring_on() const { return phase == 1; }
+        bool current() const { return forced >= 0 ? forced != 0 : (phase == 3 ? choice : measuring_on()); }
         void restart() {
             phase = 0;
             seen = settled_frames = 0;
             sum[0] = sum[1] = 0;
-            count[0] = count[1] = 0;
+            count = 0;
             ++round;
         }
-        // a retired frame's blend time (ms), the setting and the round it ran with
-        void sample(float ms, bool lockstep, uint32_t frame_round) {
+        // a retired frame: the time since the previous completion (ms), the setting and the round it ran with
+        void sample(float interval_ms, bool lockstep, uint32_t frame_round) {
             if (forced >= 0) return;
-            if (phase == 2) {
+            if (phase == 3) {
                 if (++settled_frames >= kPeriod) restart();
                 return;
             }
-            if (frame_round != round || lockstep != (phase == 1) || !(ms > 0.0f)) return;  // a frame of before the switch
+            if (frame_round != round || lockstep != measuring_on()) return;  // a frame of before the switch
             if (++seen <= (uint32_t)kSkip) return;
-            sum[phase] += ms;
-            if (++count[phase] < kSamples) return;
-            if (phase == 0) {
-                phase = 1;
-                seen = 0;
-                ++round;
-            } else {
-                choice = sum[1] / count[1] < sum[0] / count[0];
-                phase = 2;
+            sum[measuring_on() ? 1 : 0] += interval_ms;
+            if (++count < (phase == 1 ? 2 * kWindow : kWindow)) return;
+            count = 0;
+            seen = 0;
+            ++round;
+            if (++phase == 3) {
+                choice = sum[1] < 0.97 * sum[0];
                 settled_frames = 0;
-                ++round;
             }
         }
     } tuner;
@@ -1305,8 +1312,6 @@ struct gs_renderer {
             st.ms_tile_boundary = 0.0f;
             st.ms_render = span(5, 7);
         }
-        // the blend tuner's sample: the blend's own span where the passes are timed, the frame's otherwise
-        tuner.sample(sl.timed ? st.ms_render : st.ms_total, sl.lockstep, sl.tune_round);
         st.retries = retries;
         last = st;
         have_frame = true;
@@ -1322,6 +1327,7 @@ struct gs_renderer {
                 if (hipEventElapsedTime(&dt, slots[latest_done % kSlots].ev[7], sl.ev[7]) == hipSuccess) {
                     if (intervals.size() >= kIntervalRing) intervals.erase(intervals.begin(), intervals.begin() + kIntervalRing / 2);
                     intervals.push_back(dt > 0.0f ? dt : 0.0f);  // 0: it had already finished when its predecessor did
+                    tuner.sample(dt > 0.0f ? dt : 0.0f, sl.lockstep, sl.tune_round);  // the blend tuner compares completion rates
                     if (dt > 0.0f) latest_done = idx;
                 }
             } else {
@@ -1720,7 +1726,7 @@ int gs_get_blend_lockstep(gs_renderer* r, int* settled) {
     const int rc = guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "null argument");
         now = r->tuner.current() ? 1 : 0;
-        if (settled) *settled = (r->tuner.forced >= 0 || r->tuner.phase == 2) ? 1 : 0;
+        if (settled) *settled = (r->tuner.forced >= 0 || r->tuner.phase == 3) ? 1 : 0;
     });
     return rc != 0 ? rc : now;
 }
