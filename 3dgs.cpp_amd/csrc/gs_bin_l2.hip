@@ -640,7 +640,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // bucket start + that count.  Buckets hold two or three elements when the depths are spread over the bin's range; when
     // they are not (a bucket of more than kMsdBucketMax: the candidates of a wall seen face on) the stable passes take over.
     // Equal keys end up adjacent in an arbitrary order either way: the tie step below puts them in id order.
-    constexpr uint32_t kMsdBuckets = 4096, kMsdBucketMax = 64, kMsdPer = kMsdBuckets / THREADS;
+    constexpr uint32_t kMsdBuckets = 4096, kMsdBucketMax = 64;
     uint32_t* const m_cnt = smem + 2 * MAXC;                                                  // [4096] u16, two to a word
     uint16_t* const m_start = reinterpret_cast<uint16_t*>(smem + 2 * MAXC + kMsdBuckets / 2);  // [4096] u16 bucket starts
     static_assert(kMsdBuckets * 4 <= L::TAIL * 4, "the bucket tables live in the counters' area");
@@ -764,7 +764,6 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     // ---- a bin beyond MAXC: its depth range, the bucket histogram, the per-tile totals, the slabs
     uint32_t n_slabs = 1, g_kmin = 0;
     int g_sh = 0;
-    bool published = false;  // MODE 3: this bin wrote descriptors (they need the release before the bin counts as done)
     auto plan_bin = [&]() {
     if constexpr (MODE == 1 || MODE == 3) if (!slab_item && multi) {
         uint32_t lo = 0xFFFFFFFFu, hi = 0u;
@@ -936,7 +935,6 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
                         __hip_atomic_store(&a.slabs[dbase + k].ready, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and they have left before this bin counts as planned
                 }
-                published = true;
             }
         }
         n_slabs = 0;  // nothing more to do for this bin here
@@ -996,7 +994,6 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             uint32_t k[HR], b[HR];
 #pragma unroll
             for (int r = 0; r < HR; ++r) {
-                const uint32_t e = (h + r) * THREADS + tid;
                 k[r] = 0;
                 b[r] = 0;
                 if (h + r < rounds) {
@@ -1268,7 +1265,6 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
             const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_item);
             if (item < n_bins) {  // ---- a bin
                 slab_item = false;
-                published = false;
                 bin = screen_bin((uint32_t)q_order[item]);
                 bin_extent();
                 c = multi ? 0u : c_total;

@@ -347,7 +347,7 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
         // L2 instead of up to four).  Where the blend is bound by the L1-miss traffic (trained-like scenes: long lists of which a
         // quadrant keeps one entry in seven, T(6e6): 5.3 TB/s of L2 reads either way) this is worth 25 % of the kernel; where it is
         // bound by the pair loop (S scenes) the waves wait for the slowest of four at every chunk and lose 9 %.  The renderer
-        // measures both and keeps the faster (gs_capi.cpp: BlendTuner); the frames are bit-identical.
+        // measures both and keeps the faster (gs_renderer.cpp: BlendTuner); the frames are bit-identical.
         if (lockstep) __builtin_amdgcn_s_barrier();
         const BlendEntry cur = nxt;
         const uint32_t g_cur = g_nxt;  // GUARD: this chunk's Gaussian ids (for the wave's list of kept entries)
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         vis_count[(uint32_t)tid * kVisCounterStride + 1] = vis_count[(uint32_t)tid * kVisCounterStride];
         vis_count[(uint32_t)tid * kVisCounterStride] = 0;
     }
-    // XCD-aware, load-balanced tile order: a host-built table (gs_capi.cpp, ensure_tile_order)
+    // XCD-aware, load-balanced tile order: a host-built table (gs_renderer.cpp, ensure_tile_order)
     const uint32_t tile = tile_order[blockIdx.x];
     const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const uint32_t qx0 = tile_x * kTile + (w & 1) * 8, qy0 = tile_y * kTile + (w >> 1) * 8;

@@ -1,0 +1,58 @@
+// gs_blend_tuner.h -- which of the blend's two schedules a renderer runs (gs_blend.hip: the four waves of a tile in
+// LOCKSTEP over the chunks of its list, or each at its own pace), decided by measurement.  Plain C++ without a device in
+// sight: tests/test_blend_tuner.py drives it on the CPU with synthetic completion times.
+#pragma once
+
+#include <cstdint>
+
+namespace gs_host {
+
+struct BlendTuner {
+    // What is compared is the rate at which frames COMPLETE under each setting -- the interval between the completions of consecutive
+    // frames (GPU timestamps), summed over a window -- not the blend's own span: with frames in flight a kernel's span says how much
+    // of the chip it was given, not what it cost (measured: on the S scenes the lockstepped blend's span is the shorter one with
+    // three frames in flight while the frame rate is 5 % lower).  Per setting: kSkip frames ignored after the switch (frames of the
+    // other setting are still in flight beside them), kSamples intervals summed.  Lockstep has to win by 3 %: off is the safe side
+    // (-9 % at worst against +25 %).
+    // The windows run OFF (8) - ON (16) - OFF (8): a drift of the clocks over the measurement -- a renderer's first frames run on a chip
+    // that is still coming up -- then weighs on both settings alike (measured: with a plain off-then-on order config B picked the
+    // lockstep it loses 5 % with, three times out of four).
+    static constexpr int kSkip = 6, kWindow = 8;
+    static constexpr uint32_t kPeriod = 4096;       // settled frames between two looks
+    int forced = -1;        // -1 automatic, 0 / 1 pinned
+    int phase = 0;          // 0: off, 1: on (two windows), 2: off again, 3: settled
+    bool choice = false;    // the settled setting
+    uint32_t round = 1, seen = 0, settled_frames = 0;
+    double sum[2] = {0, 0};
+    int count = 0;
+    bool measuring_on() const { return phase == 1; }
+    bool current() const { return forced >= 0 ? forced != 0 : (phase == 3 ? choice : measuring_on()); }
+    void restart() {
+        phase = 0;
+        seen = settled_frames = 0;
+        sum[0] = sum[1] = 0;
+        count = 0;
+        ++round;
+    }
+    // a retired frame: the time since the previous completion (ms), the setting and the round it ran with
+    void sample(float interval_ms, bool lockstep, uint32_t frame_round) {
+        if (forced >= 0) return;
+        if (phase == 3) {
+            if (++settled_frames >= kPeriod) restart();
+            return;
+        }
+        if (frame_round != round || lockstep != measuring_on()) return;  // a frame of before the switch
+        if (++seen <= (uint32_t)kSkip) return;
+        sum[measuring_on() ? 1 : 0] += interval_ms;
+        if (++count < (phase == 1 ? 2 * kWindow : kWindow)) return;
+        count = 0;
+        seen = 0;
+        ++round;
+        if (++phase == 3) {
+            choice = sum[1] < 0.97 * sum[0];
+            settled_frames = 0;
+        }
+    }
+};
+
+}  // namespace gs_host

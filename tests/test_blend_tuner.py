@@ -1,0 +1,81 @@
+"""The blend's schedule tuner (3dgs.cpp_amd/csrc/gs_blend_tuner.h) on the CPU: a frame loop with a clock model in place of
+the device (tests/native/blend_tuner_sim.cpp).  No reference counterpart -- the reference has one blend schedule
+(render.comp); the frames are bit-identical under both of ours (tests/test_gpu_blend_modes.py), so all that is tested
+here is that the faster one is found, cheaply, and that a warming chip does not fool the measurement."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "3dgs.cpp_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def sim(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("tuner") / "libtuner_sim.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-shared", "-fPIC", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "native", "blend_tuner_sim.cpp"), "-o", out])
+    lib = C.CDLL(out)
+    lib.tuner_sim.restype = C.c_int
+    lib.tuner_sim.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.tuner_relook.restype = C.c_int
+    lib.tuner_relook.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.tuner_ignores_stale.restype = C.c_int
+    return lib
+
+
+def run(lib, off_ms, on_ms, ramp_from=1.0, ramp_frames=0, jitter=0.0, in_flight=3, frames=400, seed=1, forced=-1):
+    at, on = C.c_int(), C.c_int()
+    choice = lib.tuner_sim(off_ms, on_ms, ramp_from, ramp_frames, jitter, in_flight, frames, seed, forced, C.byref(at), C.byref(on))
+    return choice, at.value, on.value
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_picks_the_faster_schedule(sim, in_flight):
+    # the trained-like scenes: lockstep 25 % faster; the S scenes: 5-9 % slower
+    assert run(sim, 0.80, 0.60, in_flight=in_flight)[0] == 1
+    assert run(sim, 0.22, 0.235, in_flight=in_flight)[0] == 0
+
+
+def test_a_measurement_costs_few_frames(sim):
+    # three windows (8 + 16 + 8 frames) + 6 skipped after each switch + what is in flight: the wrong setting runs for at most
+    # 22 + in-flight frames of a renderer's first ~55
+    for in_flight in (1, 3):
+        choice, at, on = run(sim, 0.22, 0.24, in_flight=in_flight)
+        assert choice == 0 and 0 < at <= 50 + 3 * in_flight
+        assert on <= 22 + in_flight
+
+
+def test_off_is_kept_unless_lockstep_wins_by_three_percent(sim):
+    assert run(sim, 1.0, 1.0)[0] == 0
+    assert run(sim, 1.0, 0.98)[0] == 0
+    assert run(sim, 1.0, 0.96)[0] == 1
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_a_warming_chip_does_not_fool_it(sim, seed):
+    # the clocks of a fresh process come up over the first frames: intervals fall by 30 % over the measurement.  A plain
+    # off-then-on comparison credits that to lockstep; the OFF-ON-OFF windows see it on both sides.
+    assert run(sim, 0.22, 0.232, ramp_from=1.3, ramp_frames=60, jitter=0.01, seed=seed)[0] == 0
+    assert run(sim, 0.80, 0.62, ramp_from=1.3, ramp_frames=60, jitter=0.01, seed=seed)[0] == 1
+
+
+def test_a_pinned_setting_rests_the_tuner(sim):
+    assert run(sim, 1.0, 0.5, forced=0) == (0, 0, 0)
+    choice, at, _ = run(sim, 0.5, 1.0, forced=1)
+    assert (choice, at) == (1, 0)
+
+
+def test_it_looks_again_after_4096_settled_frames(sim):
+    first, relook = C.c_int(), C.c_int()
+    # lockstep first loses, then (the camera moved into a denser part of the scene) wins
+    second = sim.tuner_relook(1.0, 1.1, 0.7, 3, C.byref(first), C.byref(relook))
+    assert first.value == 0 and second == 1
+    assert 4096 <= relook.value <= 4096 + 64
+
+
+def test_frames_of_an_earlier_round_are_not_counted(sim):
+    assert sim.tuner_ignores_stale() == 1
