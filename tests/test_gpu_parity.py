@@ -433,6 +433,44 @@ def test_streamed_ply_ingest_matches_the_oracle_loader(pkg, oracle, gpu, tmp_pat
     assert e.value.code == -2
 
 
+def test_blend_tuner_looks_again_on_the_device(pkg, gpu):
+    """After 4096 settled frames the renderer measures the blend's two schedules again (gs_blend_tuner.h, kPeriod;
+    tests/test_blend_tuner.py has the logic on the CPU): the settled flag drops and comes back, and the frame before,
+    during and after the second look is the same frame."""
+    rec = pkg.synth.synth_records(20000, seed=5, kind="T")
+    scene = pkg.Scene.from_records(rec)
+    rend = pkg.Renderer(scene)
+    rend.set_exp_mode(3)
+    rend.set_blend_lockstep(-1)
+    rend.set_frames_in_flight(3)
+    w, h = 320, 240
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    first = rend.render_host(u)[0]
+    hb = _HipBuffers()
+    ptrs = [hb.alloc(w * h * 16) for _ in range(3)]
+
+    def run(n):
+        for i in range(n):
+            rend.render(u, ptrs[i % 3])
+        rend.synchronize()
+
+    run(150)
+    assert rend.blend_lockstep()[1] is True
+    settled, during = [], None
+    for _ in range(215):  # 4300 frames, looked at every 20 (a measurement lasts ~55)
+        run(20)
+        settled.append(rend.blend_lockstep()[1])
+        if not settled[-1] and during is None:
+            during = hb.download(ptrs[19 % 3], (h, w, 4), np.float32)
+    assert False in settled and settled[-1] is True
+    assert settled.index(False) >= 4096 // 20 - 8  # not before the period is over
+    np.testing.assert_array_equal(during, first)
+    np.testing.assert_array_equal(rend.render_host(u)[0], first)
+    hb.close()
+    rend.close()
+    scene.close()
+
+
 def test_frame_intervals_track_completions(pkg, gpu):
     """gs_get_frame_intervals: one completion-to-completion interval per consecutive pair of retired frames, positive,
     and consistent with the wall clock of the queued batch."""
