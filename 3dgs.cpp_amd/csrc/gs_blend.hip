@@ -303,6 +303,95 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
     return event;
 }
 
+// The same loop for the EXACT mode (EXP = 2, no guard: libm's expf restated in binary64, gs_expf_libm, and render.comp:87 as written --
+// every product of color * alpha * T and every sum rounded on its own).  No events: the loop ends with the chunk or with the quadrant's last
+// pixel.  Operation for operation the arithmetic of the compiler's form (the exact mode's frames are the reference's bit for bit either
+// way: the parity tests run in this mode); what goes is its mask traffic -- 17 scalar instructions and three taken branches per pair down to
+// 7 and one.  Registers: v[52:63] clobbered -- the record in v[54:63]; binary64 temporaries in the even-aligned pairs v[52:53] (the table
+// entry, then y), v[54:55] (kd, then the cubic), v[58:59] (x, r, r s) as the record's fields retire.
+#ifndef GS_BLEND_ASM_LOOP_EXACT
+#define GS_BLEND_ASM_LOOP_EXACT 1  // 0 (A/B builds): the compiler's form of the exact mode's pair loop
+#endif
+#ifndef GS_BLEND_EXECZ_BRANCH_EXACT
+#define GS_BLEND_EXECZ_BRANCH_EXACT 1  // the exp section is thirty issue slots here: pairs no pixel keeps branch over it
+#endif
+__device__ __forceinline__ void blend_pair_loop_exact(uint32_t slab_addr, const uint32_t rem, uint64_t& alive, const float fx, const float fy,
+                                                      float& T, float& c0, float& c1, float& c2, const uint2* __restrict__ tab) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;  // gs_expf_libm's constants
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0, C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    const float k1e4 = 0.0001f;
+    uint64_t saved, mk;
+    uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
+    const uint32_t tab_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)tab);  // (wave-uniform: the wave's copy in LDS)
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[alive]\n"
+        ".Lgs_xpair_%=:\n\t"
+        "ds_read_b128 v[54:57], %[addr]\n\t"
+        "ds_read_b128 v[58:61], %[addr] offset:1024\n\t"
+        "ds_read_b64 v[62:63], %[addr] offset:2048\n\t"
+        "v_add_u32 %[addr], 16, %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v58, v58, %[fx]\n\t"           // dx = u - x
+        "v_sub_f32 v59, v59, %[fy]\n\t"           // dy = v - y
+        "v_mul_f32 v54, v54, v58\n\t"             // c00' dx
+        "v_mul_f32 v56, v56, v59\n\t"             // c11' dy
+        "v_mul_f32 v54, v58, v54\n\t"             // c00' dx dx
+        "v_mul_f32 v56, v59, v56\n\t"             // c11' dy dy
+        "v_mul_f32 v55, v55, v58\n\t"             // c01' dx
+        "v_add_f32 v54, v54, v56\n\t"             // s
+        "v_mul_f32 v55, v55, v59\n\t"             // c01' dx dy
+        "v_add_f32 v54, v55, v54\n\t"             // power = s + c01' dx dy            (render.comp:66)
+        "v_cmpx_ge_f32 vcc, 0, v54\n\t"           // power <= 0 (false for NaN)        (render.comp:68)
+        "v_cmpx_nlt_f32 vcc, v54, v63\n\t"        // !(power < alpha cut)              (render.comp:78, decided on power)
+#if GS_BLEND_EXECZ_BRANCH_EXACT
+        "s_cbranch_execz .Lgs_xskip_%=\n\t"
+#endif
+        "v_cvt_f64_f32 v[58:59], v54\n\t"                          // gs_expf_libm(power):  xd
+        "v_fma_f64 v[54:55], %[iln], v[58:59], %[shift]\n\t"       // kd = fma(InvLn2N, xd, SHIFT): k in the low mantissa bits
+        "v_and_b32 v63, 31, v54\n\t"
+        "v_lshl_add_u32 v63, v63, 3, %[tab]\n\t"
+        "ds_read_b64 v[52:53], v63\n\t"                            // t = tab[k & 31]
+        "v_lshlrev_b32 v56, 15, v54\n\t"                           // k << 47, its upper word
+        "v_add_f64 v[54:55], v[54:55], -%[shift]\n\t"              // kd - SHIFT
+        "v_fma_f64 v[58:59], v[58:59], %[iln], -v[54:55]\n\t"      // r = fma(InvLn2N, xd, -kd)
+        "v_fma_f64 v[54:55], %[C0], v[58:59], %[C1]\n\t"           // q = (C0 r + C1) r + C2
+        "v_fma_f64 v[54:55], v[54:55], v[58:59], %[C2]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_u32 v53, v56, v53\n\t"                              // s = t + (k << 47)
+        "v_mul_f64 v[58:59], v[58:59], v[52:53]\n\t"               // r s
+        "v_fma_f64 v[52:53], v[54:55], v[58:59], v[52:53]\n\t"     // y = fma(q, r s, s)
+        "v_cvt_f32_f64 v54, v[52:53]\n\t"                          // the one rounding to binary32
+        "v_mul_f32 v54, v57, v54\n\t"             // o e
+        "v_min_f32 v54, 0x3f7d70a4, v54\n\t"      // alpha = min(0.99, .)             (render.comp:77)
+        "v_sub_f32 v55, 1.0, v54\n\t"             // 1 - alpha
+        "v_mul_f32 v55, %[T], v55\n\t"            // test_T = T (1 - alpha)
+        "v_cmp_gt_f32 %[mk], %[k1e4], v55\n\t"    // test_T < 1e-4: the pixel is done   (render.comp:83; under exec = m2)
+        "s_andn2_b64 exec, exec, %[mk]\n\t"
+        "v_mul_f32 v60, v60, v54\n\t"             // color * alpha * T, left to right    (render.comp:87)
+        "v_mul_f32 v61, v61, v54\n\t"
+        "v_mul_f32 v62, v62, v54\n\t"
+        "v_mul_f32 v60, %[T], v60\n\t"
+        "v_mul_f32 v61, %[T], v61\n\t"
+        "v_mul_f32 v62, %[T], v62\n\t"
+        "v_add_f32 %[c0], %[c0], v60\n\t"
+        "v_add_f32 %[c1], %[c1], v61\n\t"
+        "v_add_f32 %[c2], %[c2], v62\n\t"
+        "v_mov_b32 %[T], v55\n\t"
+        "s_andn2_b64 %[alive], %[alive], %[mk]\n\t"
+        "s_cselect_b32 %[rem], %[rem], 0\n"          // the quadrant's last pixel is done: this was the last pair
+        ".Lgs_xskip_%=:\n\t"
+        "s_mov_b64 exec, %[alive]\n\t"
+        "s_add_u32 %[rem], %[rem], -1\n\t"         // carry = there was another pair
+        "s_cbranch_scc1 .Lgs_xpair_%=\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [T] "+v"(T), [addr] "+v"(slab_addr), [alive] "+s"(alive), [rem] "+s"(left),
+          [mk] "=&s"(mk), [sv] "=&s"(saved)
+        : [fx] "v"(fx), [fy] "v"(fy), [k1e4] "s"(k1e4), [tab] "s"(tab_addr), [iln] "s"(InvLn2N), [shift] "v"(SHIFT), [C0] "s"(C0), [C1] "v"(C1),
+          [C2] "v"(C2)
+        : "vcc", "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+
 // One pass of a wave over its tile's list: returns false if the quadrant has to be re-rendered exactly (GUARD only; c0..c2
 // are then meaningless).  slab: this wave's three planes of 64 float4 {c00' c01' c11' o} {u v r g} {b, cut, -, -} --
 // plane-major keeps the staging ds_write_b128 conflict-free (lane stride 16 B); one scalar-derived address + constant offsets
@@ -316,9 +405,10 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                                            uint32_t& resolved, bool& table_ready, const bool lockstep) {
     const uint2* __restrict__ exptab = exptab_rw;
 #if defined(GS_BLEND_STATS)
-    constexpr bool kAsmLoop = false;  // (the work counters live in the compiler's form of the loop)
+    constexpr bool kAsmLoop = false, kAsmLoopExact = false;  // (the work counters live in the compiler's form of the loop)
 #else
     constexpr bool kAsmLoop = GUARD && EXP == 1 && !CONTRACT && GS_BLEND_ASM_LOOP != 0;
+    constexpr bool kAsmLoopExact = !GUARD && EXP == 2 && !CONTRACT && GS_BLEND_ASM_LOOP_EXACT != 0;
 #endif
     float T = 1.0f;
     c0 = c1 = c2 = 0.0f;
@@ -464,6 +554,15 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
                 if (alive == 0 || rem == 0) break;
                 --rem;
             }
+        } else if constexpr (kAsmLoopExact) {
+            const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm0, 0u));
+            if (keep) {  // staged in rank order, the conic pre-scaled (see below)
+                slab[0][r] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
+                slab[1][r] = cur.uv;
+                slab[2][r] = make_float4(cur.bc.x, cut, 0.0f, 0.0f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            blend_pair_loop_exact((uint32_t)(uintptr_t)&slab[0][0], (uint32_t)__popcll(bm0) - 1u, alive, fx, fy, T, c0, c1, c2, exptab);
         } else {
         // conic pre-scaled once per entry: (-c00/2, -c01, -c11/2).  Scaling by a power of two commutes with every
         // rounding below, so power is bit-identical to render.comp:66 evaluated as written while the per-pixel body
