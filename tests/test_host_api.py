@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.binding.SYMBOLS) == declared
 
 
+def test_public_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/gs3d_hip.h must compile as strict C99 on its own (what a cgo / JNI / ctypes
+    binding generator would feed it to), with no C++ or HIP types in any signature."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "gs3d_hip.h"\nint main(void) { gs_uniforms u; gs_frame_stats s; (void)u; (void)s; return (int)sizeof(gs_camera) == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+    code = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "gs3d_hip.h")).read(), flags=re.S)
+    assert "hipStream_t" not in code and "torch" not in code and "std::" not in code
+
+
 def test_struct_layouts(pkg):
     assert pkg.binding.UNIFORMS_DT.itemsize == 160  # std140 block, Renderer.h:21-29
     assert pkg.binding.CAMERA_DT.itemsize == 40
