@@ -16,7 +16,7 @@ struct BlendTuner {
     // (-9 % at worst against +25 %).
     // The windows run OFF (8) - ON (16) - OFF (8): a drift of the clocks over the measurement -- a renderer's first frames run on a chip
     // that is still coming up -- then weighs on both settings alike (measured: with a plain off-then-on order config B picked the
-    // lockstep it loses 5 % with, three times out of four).
+    // lockstep it loses 5 % with, three times out of four).  A win for lockstep has to be CONFIRMED by a second pass (won_once).
     static constexpr int kSkip = 6, kWindow = 8;
     static constexpr uint32_t kPeriod = 4096;       // settled frames between two looks
     int forced = -1;        // -1 automatic, 0 / 1 pinned
@@ -27,7 +27,12 @@ struct BlendTuner {
     int count = 0;
     bool measuring_on() const { return phase == 1; }
     bool current() const { return forced >= 0 ? forced != 0 : (phase == 3 ? choice : measuring_on()); }
+    bool won_once = false;  // lockstep won the pass before this one: a second pass has to agree before it is switched on
     void restart() {
+        begin_pass();
+        won_once = false;
+    }
+    void begin_pass() {
         phase = 0;
         seen = settled_frames = 0;
         sum[0] = sum[1] = 0;
@@ -49,7 +54,16 @@ struct BlendTuner {
         seen = 0;
         ++round;
         if (++phase == 3) {
-            choice = sum[1] < 0.97 * sum[0];
+            // ON needs two passes that agree (windows of 8 to 16 frames are a few milliseconds on the 6 M scenes: one pass in five called
+            // a tie for lockstep there, at 3 % of the frame rate); OFF, the safe side, is taken at once
+            const bool wins = sum[1] < 0.97 * sum[0];
+            if (wins && !won_once) {
+                won_once = true;
+                begin_pass();  // (++round again: harmless, frames of the old round are ignored either way)
+                return;
+            }
+            choice = wins;
+            won_once = false;
             settled_frames = 0;
         }
     }

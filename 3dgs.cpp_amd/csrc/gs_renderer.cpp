@@ -209,7 +209,7 @@ struct gs_renderer {
     // The blend's LOCKSTEP (gs_blend.hip): the four waves of a tile take every chunk of its list together, so that their gathers of the
     // same records meet in L1.  Worth +25 % of the blend on trained-like scenes (L1-miss-bound: T(6e6) 505 -> 378 us; T(1e6) with three
     // frames in flight 2 675 -> 3 575 frames/s), -9 % on the S scenes (pair-loop-bound).  Nothing the renderer knows up front tells the
-    // two apart, so it MEASURES: sixteen frames each way (the rate at which frames complete; the frames are bit-identical either way), keeps
+    // two apart, so it MEASURES (gs_blend_tuner.h: the rate at which frames complete over OFF - ON - OFF windows; the frames are bit-identical either way), keeps
     // lockstep where it wins by 3 %, and looks again every 4096 frames or when the frame's shape changes.  GS_BLEND_LOCKSTEP=0 / 1 (or gs_set_blend_lockstep)
     // pins it; the tuner then rests.
     BlendTuner tuner;

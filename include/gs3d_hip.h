@@ -243,8 +243,9 @@ int gs_set_graph_mode(gs_renderer* r, int enabled);
  * chunk), so that their gathers of the same splat records meet in the CU's L1.  It changes no pixel (the frames are bit-identical
  * either way), only where the time goes: +25 % of the blend on trained-like scenes (long lists of which an 8 x 8 quadrant keeps one
  * entry in seven: the kernel is bound by its L1 misses), -9 % on scenes whose blend is bound by the pair loop.  mode -1 (default):
- * the renderer measures both over a few frames -- the blend's own span -- keeps the faster and looks again every 4096 frames or
- * when the frame's size changes; 0 / 1: pinned off / on (also GS_BLEND_LOCKSTEP=0 / 1 at renderer creation). */
+ * the renderer measures the rate at which frames complete under both settings over its first 60 to 130 frames, switches lockstep
+ * on only where it wins by 3 % in two passes running, and looks again every 4096 frames or when the frame's size changes;
+ * 0 / 1: pinned off / on (also GS_BLEND_LOCKSTEP=0 / 1 at renderer creation). */
 int gs_set_blend_lockstep(gs_renderer* r, int mode);
 /* The setting the next frame will run with (0 / 1; negative: error); *settled (nullable) = 1 once the measurement has decided
  * (or the mode is pinned). */

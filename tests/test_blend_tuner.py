@@ -47,6 +47,10 @@ def test_a_measurement_costs_few_frames(sim):
         choice, at, on = run(sim, 0.22, 0.24, in_flight=in_flight)
         assert choice == 0 and 0 < at <= 50 + 3 * in_flight
         assert on <= 22 + in_flight
+        # a win for lockstep is confirmed by a second pass before it is taken: twice the frames, half of them already in lockstep
+        choice, at, on = run(sim, 0.80, 0.60, in_flight=in_flight)
+        assert choice == 1 and 50 < at <= 2 * (50 + 3 * in_flight)
+        assert 2 * 22 <= on <= 2 * (22 + in_flight)
 
 
 def test_off_is_kept_unless_lockstep_wins_by_three_percent(sim):
@@ -61,6 +65,13 @@ def test_a_warming_chip_does_not_fool_it(sim, seed):
     # off-then-on comparison credits that to lockstep; the OFF-ON-OFF windows see it on both sides.
     assert run(sim, 0.22, 0.232, ramp_from=1.3, ramp_frames=60, jitter=0.01, seed=seed)[0] == 0
     assert run(sim, 0.80, 0.62, ramp_from=1.3, ramp_frames=60, jitter=0.01, seed=seed)[0] == 1
+
+
+def test_a_tie_is_rarely_called_for_lockstep_by_noise(sim):
+    # equal costs, +-10 % jitter on every completion interval: a single OFF-ON-OFF pass calls it for lockstep in 5.5 % of 400 seeded runs
+    # (measured with the one-pass form of the tuner), the confirmed decision in 0.5 %.  (Deterministic: the clock model is seeded.)
+    false_on = sum(run(sim, 0.53, 0.53, jitter=0.10, frames=600, seed=seed)[0] == 1 for seed in range(400))
+    assert false_on <= 4
 
 
 def test_a_pinned_setting_rests_the_tuner(sim):

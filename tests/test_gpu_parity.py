@@ -454,16 +454,16 @@ def test_blend_tuner_looks_again_on_the_device(pkg, gpu):
             rend.render(u, ptrs[i % 3])
         rend.synchronize()
 
-    run(150)
+    run(240)  # (settled: one pass of ~55 frames, or two if lockstep wins the first)
     assert rend.blend_lockstep()[1] is True
     settled, during = [], None
-    for _ in range(215):  # 4300 frames, looked at every 20 (a measurement lasts ~55)
+    for _ in range(222):  # 4440 frames, looked at every 20 (a measurement lasts 55 to 110)
         run(20)
         settled.append(rend.blend_lockstep()[1])
         if not settled[-1] and during is None:
             during = hb.download(ptrs[19 % 3], (h, w, 4), np.float32)
     assert False in settled and settled[-1] is True
-    assert settled.index(False) >= 4096 // 20 - 8  # not before the period is over
+    assert 1 + 240 + 20 * (settled.index(False) + 1) >= 4096  # frames rendered when the second look was first seen: not before the period is over
     np.testing.assert_array_equal(during, first)
     np.testing.assert_array_equal(rend.render_host(u)[0], first)
     hb.close()

@@ -15,8 +15,8 @@ mkdir -p "$OUT"
 python -c "import __graft_entry__ as e; print(e.load_package().binding.library_source_hash())" > "$OUT/source_hash.txt"
 cd /tmp && export TMPDIR=/tmp
 # counter passes: enough untimed frames ahead of the three counted ones that the renderer has settled -- the depth-order level (config C
-# refines its bins and steps down to k_bin_fast<12> on the first clean frame), and the blend's lockstep, which it measures over ~25 frames
-PW=${GS_PROFILE_WARM:-40}
+# refines its bins and steps down to k_bin_fast<12> on the first clean frame), and the blend's lockstep, which it measures over 55 to 125 frames
+PW=${GS_PROFILE_WARM:-140}
 PMC="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"
 for W in $WL; do
   case $W in
@@ -29,8 +29,8 @@ for W in $WL; do
   D="python $R/tools/tune_sweep.py --no-prime --batches 1 $ARGS"
   O=$OUT/$W
   mkdir -p "$O"/{default,serial,pmc,fetch,write}
-  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/serial" -o s -- $D --fif 1 --frames $FR --json-out "$O/serial/bench.json" > /dev/null 2>&1
-  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/default" -o d -- $D --fif 3 --frames $FR --json-out "$O/default/bench.json" > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/serial" -o s -- $D --fif 1 --frames $FR --warm $PW --json-out "$O/serial/bench.json" > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/default" -o d -- $D --fif 3 --frames $FR --warm $PW --json-out "$O/default/bench.json" > /dev/null 2>&1
   timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc" -o p -- $D --fif 1 --frames 3 --warm $PW > /dev/null 2>&1
   timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -o f -- $D --fif 1 --frames 3 --warm $PW > /dev/null 2>&1
   timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write" -o w -- $D --fif 1 --frames 3 --warm $PW > /dev/null 2>&1
@@ -39,7 +39,7 @@ for W in $WL; do
     timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc_exact" -o p -- $D --fif 1 --frames 3 --warm $PW --exp-mode 2 > /dev/null 2>&1
     timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc_hw" -o p -- $D --fif 1 --frames 3 --warm $PW --exp-mode 1 > /dev/null 2>&1
     timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc_fast" -o p -- $D --fif 1 --frames 3 --warm $PW --exp-mode 0 --contract 1 > /dev/null 2>&1
-    timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/serial_exact" -o s -- $D --fif 1 --frames $FR --exp-mode 2 --json-out "$O/serial_exact/bench.json" > /dev/null 2>&1
+    timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/serial_exact" -o s -- $D --fif 1 --frames $FR --warm $PW --exp-mode 2 --json-out "$O/serial_exact/bench.json" > /dev/null 2>&1
   fi
 done
 # per-dispatch traces are large; the stats and counter CSVs are what is summarised
