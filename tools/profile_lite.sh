@@ -29,6 +29,11 @@ for W in $WL; do
   D="python $R/tools/tune_sweep.py --no-prime --batches 1 $ARGS"
   O=$OUT/$W
   mkdir -p "$O"/{default,serial,pmc,fetch,write}
+  # The blend's lockstep is the renderer's own choice, measured over its first 60-130 frames -- frames a profiler would average into every
+  # kernel's row.  One unprofiled run reads the choice (three in flight, as shipped); the profiled runs below are PINNED to it.
+  LS=$(timeout 120 $D --fif 3 --frames 200 2> /dev/null | grep "^fif" | tail -1 | grep -o "lockstep [A-Za-z]*" | cut -d" " -f2)
+  case "$LS" in True) export GS_BLEND_LOCKSTEP=1;; False) export GS_BLEND_LOCKSTEP=0;; *) unset GS_BLEND_LOCKSTEP;; esac
+  echo "${LS:-unknown}" > "$O/lockstep.txt"
   timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/serial" -o s -- $D --fif 1 --frames $FR --warm $PW --json-out "$O/serial/bench.json" > /dev/null 2>&1
   timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/default" -o d -- $D --fif 3 --frames $FR --warm $PW --json-out "$O/default/bench.json" > /dev/null 2>&1
   timeout 120 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$O/pmc" -o p -- $D --fif 1 --frames 3 --warm $PW > /dev/null 2>&1
@@ -43,6 +48,7 @@ for W in $WL; do
   fi
 done
 # per-dispatch traces are large; the stats and counter CSVs are what is summarised
+unset GS_BLEND_LOCKSTEP
 find "$R/gpurun_out/prof_$TAG" -name '*_kernel_trace.csv' -delete
 cd "$R"
 ls -R "$OUT" | head -60

@@ -41,6 +41,12 @@ def kernel_stats(wl, sub, out_name, header):
     b = bench_line(os.path.join(src, wl, sub, "bench.json"))
     with open(os.path.join(dst, out_name), "w") as f:
         f.write("# " + header + "\n")
+        try:
+            ls = open(os.path.join(src, wl, "lockstep.txt")).read().strip()
+            f.write("# blend lockstep pinned to the renderer's own measured choice for this workload (an unprofiled run, three frames in flight): %s\n"
+                    % {"True": "on", "False": "off"}.get(ls, ls))
+        except OSError:
+            pass
         if b:
             f.write("# %s under the profiler: %s frames/s, %d frame(s) in flight; HIP-event spans (us) %s; config %s\n"
                     % (b["driver"], b["value"], b["frames_in_flight"], json.dumps(b["spans_us"]), json.dumps(b["config"])))
@@ -133,7 +139,7 @@ for wl in [d for d in ("B", "C", "T", "E") if os.path.isdir(os.path.join(src, d)
 
 if workloads:
     with open(os.path.join(dst, tag + "_pmc_counters.txt"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --pmc <counters> -- " + CMD + " --fif 1 --frames 3 --warm 40  (MI355X); three separate runs per workload:\n"
+        f.write("# rocprofv3 --kernel-trace --pmc <counters> -- " + CMD + " --fif 1 --frames 3 --warm 140  (MI355X; lockstep pinned to the renderer's measured choice); three separate runs per workload:\n"
                 "#   SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY | FETCH_SIZE | WRITE_SIZE\n"
                 "# medians over the dispatches of a run.  FETCH_SIZE / WRITE_SIZE in KB.  SQ_*_CYCLES are quad-cycles; SQ_BUSY_CYCLES is summed over 32 shader engines.\n")
         f.write("\n".join(pmc_txt) + "\n")
