@@ -31,6 +31,7 @@ for W in $WL; do
   mkdir -p "$O"/{default,serial,pmc,fetch,write}
   # The blend's lockstep is the renderer's own choice, measured over its first 60-130 frames -- frames a profiler would average into every
   # kernel's row.  One unprofiled run reads the choice (three in flight, as shipped); the profiled runs below are PINNED to it.
+  unset GS_BLEND_LOCKSTEP
   LS=$(timeout 120 $D --fif 3 --frames 200 2> /dev/null | grep "^fif" | tail -1 | grep -o "lockstep [A-Za-z]*" | cut -d" " -f2)
   case "$LS" in True) export GS_BLEND_LOCKSTEP=1;; False) export GS_BLEND_LOCKSTEP=0;; *) unset GS_BLEND_LOCKSTEP;; esac
   echo "${LS:-unknown}" > "$O/lockstep.txt"
