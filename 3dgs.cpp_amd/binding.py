@@ -125,7 +125,12 @@ def _p(a):
     builds a reference cycle per call (the pointer object keeps the array, the array's ctypes helper keeps the pointer), i.e. two
     objects of cyclic garbage per gs_render -- enough to trigger Python's full (generation-2) collection once per ~2 000 frames,
     which in a process that has imported torch walks ~170 000 objects and holds the frame loop for 35-45 ms: the "once per run"
-    stall of bench.py's rounds 2-4 (profiles/r05_stall_hunt.txt)."""
+    stall of bench.py's rounds 2-4 (profiles/r05_stall_hunt.txt).
+
+    CONTRACT: the returned pointer does NOT keep `a` alive.  Pass a NAMED array that outlives the C call -- never a temporary
+    (`_p(np.ascontiguousarray(x))` would hand C a dangling pointer).  What can be checked here is: an ndarray, C-contiguous."""
+    if not isinstance(a, np.ndarray) or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("_p() takes a C-contiguous numpy array that the caller keeps alive for the duration of the call")
     return C.c_void_p(a.ctypes.data)
 
 

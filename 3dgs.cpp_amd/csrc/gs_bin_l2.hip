@@ -1289,7 +1289,16 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
                             // every bin beyond MAXC has been planned (they head the queue, so this is early in the launch: nobody
                             // waits for the slowest ordinary bin), and every descriptor was released before its bin counted: one
                             // more look decides
+                            // The final look must not be ordered ahead of the q_bins_done load above (two relaxed loads have no
+                            // order of their own; round-5 advisor finding): the load has returned (vmcnt(0)) and the compiler may not
+                            // move the next one across this point.  Both are sc1 loads past this CU's L1: nothing to invalidate.
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             have = __hip_atomic_load(&a.slabs[d].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch ? 1u : 0u;
+                            // belt and braces: every planned bin has counted its slabs by now, so a claimed index below that count
+                            // whose descriptor is NOT ready means a slab would be dropped silently -- re-run the frame instead
+                            if (!have && d < min(__hip_atomic_load(&a.counters->slabs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.slab_capacity) &&
+                                !(__hip_atomic_load(&a.counters->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2u))
+                                atomicOr(&a.counters->overflow, 2u);
                             break;
                         }
                         if (spin > (1u << 20)) {  // (~ seconds: never expected; rather the global path than a hung queue)

