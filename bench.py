@@ -41,6 +41,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievabl
 # dense VALU load (1.09 ns per instruction and SIMD, i.e. ~1.85 GHz): a measurement, quoted beside the spec, never as it
 VALU_PEAK = 1024 * 2.4e9 / 2
 VALU_SUSTAINED = 1024 / 1.09e-9
+MIN_WARM_SECONDS = 0.3   # untimed K-step batches run at least this long (the clocks of the driver's fresh box ramp for ~50 ms: BENCH_r05's first batches)
 MIN_TIMED_SECONDS = 0.5  # a timed region shorter than this is repeated and the median batch reported
 # the blend's modes (gs_set_exp_mode, gs_set_blend_contraction).  "default" is the library's: the guarded v_exp_f32
 MODES = {"default": (3, False), "exact": (2, False), "fast": (0, True), "hw_exp": (1, True)}
@@ -233,10 +234,11 @@ def main():
     # the W warm-up steps above are the contract's; the clocks of an idle chip need longer than a few milliseconds to
     # come up (round 2: the first timed batch ran at a ninth of the median) and the renderer's blend tuner measures its two
     # schedules over its first ~130 frames, so untimed K-step batches follow until (a) three consecutive ones lie within 3 % of
-    # the RUNNING MINIMUM -- round 5 compared neighbours, which a smooth ramp satisfies: the driver's first five timed batches
-    # were 5-19 % slow -- and (b) the tuner has settled (every rank runs the same count: decided on the max over ranks)
-    best, stable, warm_batches, tuner_settled = None, 0, 0, False
-    for _ in range(80):
+    # the RUNNING MINIMUM without improving on it -- round 5 compared neighbours, which a smooth ramp satisfies: the driver's first
+    # five timed batches were 5-19 % slow -- (b) the tuner has settled, (c) MIN_WARM_SECONDS have passed (every rank runs the same
+    # count: decided on the max over ranks)
+    best, stable, warm_batches, tuner_settled, warm_s = None, 0, 0, False, 0.0
+    for _ in range(400):
         sync_all()
         tw = time.perf_counter()
         for i in range(args.steps):
@@ -249,10 +251,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtw, settled = float(t[0].item()), -float(t[1].item())
         warm_batches += 1
+        warm_s += dtw
+        # stable = this batch neither beats the minimum of the batches BEFORE it by more than 1 % (a ramp still going down: every
+        # batch of a falling ramp is its own running minimum, which the first form of this test let pass) nor lies 3 % above it
+        stable = stable + 1 if best is not None and 0.99 * best <= dtw <= 1.03 * best else 0
         best = dtw if best is None else min(best, dtw)
-        stable = stable + 1 if dtw <= 1.03 * best else 0
         tuner_settled = settled > 0
-        if stable >= 3 and tuner_settled:
+        if stable >= 4 and tuner_settled and warm_s >= MIN_WARM_SECONDS:
             break
     sync_all()
     rend.timing_totals(reset=True)

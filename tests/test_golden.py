@@ -62,3 +62,74 @@ def test_hip_reproduces_golden(pkg, gpu, gold):
     np.testing.assert_array_equal(rend.stage("sorted_gid"), gold["sorted_payload"])
     np.testing.assert_array_equal(rend.stage("ranges", u), gold["boundaries"])
     np.testing.assert_array_equal(np.ascontiguousarray(img[..., :3]).view(np.uint32), gold["image"].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The second fixture: a scene that forces DEPTH SLABS (depth-order level 4).  tests/golden/make_golden_slabs.py: 24 000 splats in
+# one bin of 4 x 4 tiles (22 496 candidates: beyond the largest in-LDS order), depths in two thin walls and a fog; outputs by the
+# reference's shader text (radix passes included), inputs regenerated from the committed generator and checked by hash.
+SLABS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_slabs24k.npz")
+
+
+@pytest.fixture(scope="module")
+def slab_gold(pkg):
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_slabs", os.path.join(os.path.dirname(SLABS), "make_golden_slabs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = dict(np.load(SLABS))
+    rec = mod.slab_scene_records(pkg)
+    assert hashlib.sha256(rec.tobytes()).hexdigest() == str(g["records_sha256"]), "the regenerated input is not what the reference text was given"
+    g["records"] = rec
+    return g
+
+
+def test_oracle_reproduces_the_slab_golden(oracle, slab_gold):
+    g = slab_gold
+    assert "src/shaders/sort/sort.comp sha256=" in str(g["generator"]) and "src/shaders/render.comp sha256=" in str(g["generator"])
+    verts = oracle.activate_records(g["records"])
+    w, h = int(g["uniforms"]["width"][0]), int(g["uniforms"]["height"][0])
+    u = oracle.camera_uniforms(g["camera"], w, h)
+    assert u.tobytes() == g["uniforms"].tobytes()
+    st = oracle.stages(verts, u)
+    np.testing.assert_array_equal(st["tiles"], g["tiles"])
+    vis = st["tiles"] > 0
+    np.testing.assert_array_equal(st["attr"]["depth"][vis].view(np.uint32), g["visible_depth"].view(np.uint32))
+    np.testing.assert_array_equal((st["sorted_keys"] >> np.uint64(32)).astype(np.uint32), g["sorted_tile"])
+    np.testing.assert_array_equal(st["sorted_payload"], g["sorted_payload"])
+    np.testing.assert_array_equal(st["boundaries"], g["boundaries"])
+    np.testing.assert_array_equal(st["image"][..., :3].view(np.uint32), g["image"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("queue", ["1", "0"], ids=["k_bin_queue", "k_bin_slabs+k_slab_work"])
+def test_hip_depth_slabs_reproduce_the_slab_golden(pkg, gpu, slab_gold, monkeypatch, queue, _sort_path):
+    """Level 4 -- one launch over the queue of bins and slabs (k_bin_queue), or round 4's two launches -- against the reference text's
+    lists and image, element for element; and the library's DEFAULT blend (the guarded v_exp_f32) within rounding noise of it."""
+    if _sort_path == "1":
+        pytest.skip("the slabs belong to the bin-local path: runs once")
+    g = slab_gold
+    monkeypatch.setenv("GS_SORT_PATH", "0")   # automatic: the bin-local path climbs to the slabs by itself
+    monkeypatch.setenv("GS_L2_QUEUE", queue)
+    w, h = int(g["uniforms"]["width"][0]), int(g["uniforms"]["height"][0])
+    scene = pkg.Scene.from_records(g["records"], device=0)
+    rend = pkg.Renderer(scene)
+    rend.set_exp_mode(2)
+    u = pkg.camera_uniforms(g["camera"].view(pkg.binding.CAMERA_DT), w, h)
+    assert u.tobytes() == g["uniforms"].tobytes()
+    img, _ = rend.render_host(u)
+    st = rend.stats()
+    assert st.sort_path == 2 and st.sort_level == 4 and st.bin_tiles == 4 and st.max_bin_entries == 22496, (st.sort_path, st.sort_level, st.bin_tiles, st.max_bin_entries)
+    np.testing.assert_array_equal(rend.stage("tiles"), g["tiles"])
+    vis = g["tiles"] > 0
+    np.testing.assert_array_equal(rend.stage("depth")[vis].view(np.uint32), g["visible_depth"].view(np.uint32))
+    np.testing.assert_array_equal(rend.stage("sorted_tile"), g["sorted_tile"])
+    np.testing.assert_array_equal(rend.stage("sorted_gid"), g["sorted_payload"])
+    np.testing.assert_array_equal(rend.stage("ranges", u), g["boundaries"])
+    np.testing.assert_array_equal(np.ascontiguousarray(img[..., :3]).view(np.uint32), g["image"].view(np.uint32))
+    rend.set_exp_mode(3)
+    img3, _ = rend.render_host(u)
+    assert float(np.abs(img3[..., :3].astype(np.float64) - g["image"]).max()) <= 1e-5
+    rend.close()
+    scene.close()
