@@ -209,18 +209,74 @@ __device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist
 // Loaded records live in v[54:63] (a 128-bit operand's components cannot be named in inline asm): clobbered, the allocator
 // keeps out.  Hazards inside the string: v_exp_f32 -> its consumer (trans op, 1 state: the s_nop); none of the others apply
 // (no DPP / readlane / VMEM here; SALU and branch reads of VALU-written VCC / EXEC / SGPRs are interlocked).
-#ifndef GS_BLEND_EXECZ_BRANCH
-#define GS_BLEND_EXECZ_BRANCH 0  // 0: no s_cbranch_execz -- the 6 % of the pairs no pixel keeps run the exp section with exec = 0 (every VALU a no-op,
-                                 // mk = sl = 0); 1 (A/B) the branch.  Config B, serial blend: 168 -> 166.5 us
-#endif
-#ifndef GS_BLEND_TAIL_CSELECT
-#define GS_BLEND_TAIL_CSELECT 1  // 1: "the last pixel died" folds into the count (s_cselect: the loop ends at its own test) instead of a branch
-                                 // of its own; with the line above 168 -> 166 us (alone: neutral)
-#endif
+// Round 6: three things less per pair.  (1) ONE compare decides render.comp:68 and :78: the conic is staged with its signs as
+// they are ((c00/2, c01, c11/2) instead of the negated triple), so the chain yields pn = -power -- the same magnitudes, every
+// rounding mirrored -- and the slab holds ncut = -cut >= +0.  power <= 0 and power >= cut  <=>  +0 <= pn <= ncut, and for binary32
+// values that is ONE unsigned compare of the bit patterns: a negative pn (power > 0) has the sign bit set and compares above every
+// ncut <= +inf, so does every NaN, and pn is never -0 (it is a sum whose first operand, c00' dx dx + c11' dy dy, is >= +0 for the
+// c00, c11 >= +0 that preprocess produces from a > 0, c > 0, det > 0; x + y is -0 only for -0 + -0).  (2) The loop is unrolled by
+// four over immediate ds_read offsets: the address moves once per four pairs and three of four back edges are not-taken
+// branches.  (3) the exp's argument is pn * (-log2 e): the sign costs nothing.
+// 24 - 0.75 vector + 7 scalar instructions per pair (round 5: 25 + 7); same arithmetic: frames bit-identical (tools/ab_image_check.py).
 struct PairLoopEvent {
     uint64_t m2, mk, sl;   // lanes that evaluated exp; of those: T (1 - alpha) < 1e-4 with the fast exp; inside the slice
     float w;               // alpha * T(before) -- valid in the lanes of m2 (the entry's colour is re-read from the slab: 3 % of the pairs)
 };
+#define GS_STR_(x) #x
+#define GS_STR(x) GS_STR_(x)
+// one pair of the unrolled loop: J = 0..3, the three planes of entry J behind the address at J*16, 1024 + J*16, 2048 + J*16
+#define GS_PAIR_HEAD(J)                                                                                                       \
+        ".Lgs_pair" GS_STR(J) "_%=:\n\t"                                                                                      \
+        "ds_read_b128 v[54:57], %[addr] offset:" GS_STR(J) "*16\n\t"                                                          \
+        "ds_read_b128 v[58:61], %[addr] offset:1024+" GS_STR(J) "*16\n\t"                                                     \
+        "ds_read_b64 v[62:63], %[addr] offset:2048+" GS_STR(J) "*16\n\t"                                                      \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                            \
+        "v_sub_f32 v58, v58, %[fx]\n\t"           /* dx = u - x   (the loaded registers double as temporaries) */             \
+        "v_sub_f32 v59, v59, %[fy]\n\t"           /* dy = v - y */                                                            \
+        "v_mul_f32 v54, v54, v58\n\t"             /* c00' dx */                                                               \
+        "v_mul_f32 v56, v56, v59\n\t"             /* c11' dy */                                                               \
+        "v_mul_f32 v54, v58, v54\n\t"             /* c00' dx dx */                                                            \
+        "v_mul_f32 v56, v59, v56\n\t"             /* c11' dy dy */                                                            \
+        "v_mul_f32 v55, v55, v58\n\t"             /* c01' dx */                                                               \
+        "v_add_f32 v54, v54, v56\n\t"             /* -s */                                                                    \
+        "v_mul_f32 v55, v55, v59\n\t"             /* c01' dx dy */                                                            \
+        "v_add_f32 v54, v55, v54\n\t"             /* pn = -power                          (render.comp:66) */                 \
+        "v_cmpx_le_u32 vcc, v54, v63\n\t"         /* +0 <= pn <= ncut: power <= 0 and power >= the alpha cut (render.comp:68,78) */
+#define GS_PAIR_GUARDED(J)                                                                                                    \
+        GS_PAIR_HEAD(J)                                                                                                       \
+        "v_mul_f32 v56, 0xbfb8aa3b, v54\n\t"      /* power log2 e */                                                          \
+        "v_exp_f32 v56, v56\n\t"                                                                                              \
+        "s_nop 0\n\t"                                                                                                         \
+        "v_mul_f32 v56, v57, v56\n\t"             /* o e' */                                                                  \
+        "v_min_f32 v56, 0x3f7d70a4, v56\n\t"      /* alpha = min(0.99, .)             (render.comp:77) */                     \
+        "v_sub_f32 v55, 1.0, v56\n\t"             /* 1 - alpha */                                                             \
+        "v_mul_f32 %[w], v56, %[T]\n\t"           /* alpha T: the weight of this entry (the T of before) */                   \
+        "v_mul_f32 %[T], %[T], v55\n\t"           /* test_T = T (1 - alpha), in place */                                      \
+        "v_cmp_gt_f32 %[mk], %[k1e4], %[T]\n\t"   /* test_T < 1e-4                     (render.comp:83) */                    \
+        "v_cmp_eq_u32_sdwa vcc, %[T], %[slice] src0_sel:WORD_1 src1_sel:DWORD\n\t"  /* ... any of them inside the guard's slice? */ \
+        "s_cbranch_vccnz .Lgs_slice" GS_STR(J) "_%=\n"                                                                        \
+        ".Lgs_cont" GS_STR(J) "_%=:\n\t"                                                                                      \
+        "s_andn2_b64 exec, exec, %[mk]\n\t"                                                                                   \
+        "v_fmac_f32 %[c0], v60, %[w]\n\t"         /* render.comp:87 (the guarded mode's fused form) */                        \
+        "v_fmac_f32 %[c1], v61, %[w]\n\t"                                                                                     \
+        "v_fmac_f32 %[c2], v62, %[w]\n\t"                                                                                     \
+        "s_andn2_b64 %[alive], %[alive], %[mk]\n\t"                                                                           \
+        "s_cselect_b32 %[rem], %[rem], 0\n\t"     /* the quadrant's last pixel has saturated: this was the last pair */       \
+        "s_mov_b64 exec, %[alive]\n\t"                                                                                        \
+        "s_add_u32 %[rem], %[rem], -1\n\t"        /* carry = there was another pair */
+// a lane of m2 inside the slice: inside the guard's COARSE window as well?  (under exec = m2: bits of m2's lanes only.)  No: every
+// decision of this pair is the fast arithmetic's, carry on (T(6e6): most slice hits end here).  Yes: leave with the pending pair --
+// exec restored FIRST (the address register belongs to every lane), then the address put past the pair.
+#define GS_PAIR_SLICE(J)                                                                                                      \
+        ".Lgs_slice" GS_STR(J) "_%=:\n\t"                                                                                     \
+        "v_cmp_le_f32 %[sl], %[klo], %[T]\n\t"                                                                                \
+        "v_cmp_gt_f32 %[m2], %[khi], %[T]\n\t"                                                                                \
+        "s_and_b64 %[sl], %[sl], %[m2]\n\t"                                                                                   \
+        "s_cbranch_scc0 .Lgs_cont" GS_STR(J) "_%=\n\t"                                                                        \
+        "s_mov_b64 %[m2], exec\n\t"                                                                                           \
+        "s_mov_b64 exec, %[sv]\n\t"                                                                                           \
+        "v_add_u32 %[addr], 16+" GS_STR(J) "*16, %[addr]\n\t"                                                                 \
+        "s_branch .Lgs_event_%=\n"
 // slab_addr: LDS byte address of the next entry's {c00' c01' c11' o} (the other two planes 1024 and 2048 bytes behind it);
 // rem: pairs left in the chunk MINUS ONE.  Returns 0 when the chunk is exhausted or alive == 0, 1 with `ev` filled (rem then
 // still counts the pending pair, slab_addr is already past it).
@@ -235,65 +291,26 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[alive]\n"
-        ".Lgs_pair_%=:\n\t"
-        "ds_read_b128 v[54:57], %[addr]\n\t"
-        "ds_read_b128 v[58:61], %[addr] offset:1024\n\t"
-        "ds_read_b64 v[62:63], %[addr] offset:2048\n\t"
-        "v_add_u32 %[addr], 16, %[addr]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_sub_f32 v58, v58, %[fx]\n\t"           // dx = u - x   (the loaded registers double as temporaries)
-        "v_sub_f32 v59, v59, %[fy]\n\t"           // dy = v - y
-        "v_mul_f32 v54, v54, v58\n\t"             // c00' dx
-        "v_mul_f32 v56, v56, v59\n\t"             // c11' dy
-        "v_mul_f32 v54, v58, v54\n\t"             // c00' dx dx
-        "v_mul_f32 v56, v59, v56\n\t"             // c11' dy dy
-        "v_mul_f32 v55, v55, v58\n\t"             // c01' dx
-        "v_add_f32 v54, v54, v56\n\t"             // s
-        "v_mul_f32 v55, v55, v59\n\t"             // c01' dx dy
-        "v_add_f32 v54, v55, v54\n\t"             // power = s + c01' dx dy            (render.comp:66)
-        "v_cmpx_ge_f32 vcc, 0, v54\n\t"           // power <= 0 (false for NaN)        (render.comp:68)
-        "v_cmpx_nlt_f32 vcc, v54, v63\n\t"        // !(power < alpha cut)              (render.comp:78, decided on power)
-#if GS_BLEND_EXECZ_BRANCH
-        "s_cbranch_execz .Lgs_skip_%=\n\t"
-#endif
-        "v_mul_f32 v56, 0x3fb8aa3b, v54\n\t"
-        "v_exp_f32 v56, v56\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f32 v56, v57, v56\n\t"             // o e'
-        "v_min_f32 v56, 0x3f7d70a4, v56\n\t"      // alpha = min(0.99, .)             (render.comp:77)
-        "v_sub_f32 v55, 1.0, v56\n\t"             // 1 - alpha
-        "v_mul_f32 %[w], v56, %[T]\n\t"           // alpha T: the weight of this entry (the T of before)
-        "v_mul_f32 %[T], %[T], v55\n\t"           // test_T = T (1 - alpha), in place
-        "v_cmp_gt_f32 %[mk], %[k1e4], %[T]\n\t"    // test_T < 1e-4                     (render.comp:83)
-        "v_cmp_eq_u32_sdwa vcc, %[T], %[slice] src0_sel:WORD_1 src1_sel:DWORD\n\t"  // ... and is any of them inside the guard's slice?
-        "s_cbranch_vccnz .Lgs_slice_%=\n"
-        ".Lgs_cont_%=:\n\t"
-        "s_andn2_b64 exec, exec, %[mk]\n\t"
-        "v_fmac_f32 %[c0], v60, %[w]\n\t"          // render.comp:87 (the guarded mode's fused form)
-        "v_fmac_f32 %[c1], v61, %[w]\n\t"
-        "v_fmac_f32 %[c2], v62, %[w]\n\t"
-        "s_andn2_b64 %[alive], %[alive], %[mk]\n\t"
-#if GS_BLEND_TAIL_CSELECT
-        "s_cselect_b32 %[rem], %[rem], 0\n"
-#else
-        "s_cbranch_scc0 .Lgs_done_%=\n"            // every pixel of the quadrant has saturated
-#endif
-        ".Lgs_skip_%=:\n\t"
-        "s_mov_b64 exec, %[alive]\n\t"
-        "s_add_u32 %[rem], %[rem], -1\n\t"         // carry = there was another pair
-        "s_cbranch_scc1 .Lgs_pair_%=\n"
+        GS_PAIR_GUARDED(0)
+        "s_cbranch_scc0 .Lgs_done_%=\n"
+        GS_PAIR_GUARDED(1)
+        "s_cbranch_scc0 .Lgs_done_%=\n"
+        GS_PAIR_GUARDED(2)
+        "s_cbranch_scc0 .Lgs_done_%=\n"
+        GS_PAIR_GUARDED(3)
+        "v_add_u32 %[addr], 64, %[addr]\n\t"
+        "s_cbranch_scc1 .Lgs_pair0_%=\n"
         ".Lgs_done_%=:\n\t"
         "s_mov_b32 %[ev], 0\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
         "s_branch .Lgs_exit_%=\n"
-        ".Lgs_slice_%=:\n\t"                        // a lane of m2 inside the slice: inside the guard's COARSE window as well?
-        "v_cmp_le_f32 %[sl], %[klo], %[T]\n\t"       // (under exec = m2: bits of m2's lanes only)
-        "v_cmp_gt_f32 %[m2], %[khi], %[T]\n\t"
-        "s_and_b64 %[sl], %[sl], %[m2]\n\t"
-        "s_cbranch_scc0 .Lgs_cont_%=\n\t"           // no: every decision of this pair is the fast arithmetic's, carry on (T(6e6): most slice hits end here)
-        "s_mov_b64 %[m2], exec\n\t"
+        GS_PAIR_SLICE(0)
+        GS_PAIR_SLICE(1)
+        GS_PAIR_SLICE(2)
+        GS_PAIR_SLICE(3)
+        ".Lgs_event_%=:\n\t"
         "s_mov_b32 %[ev], 1\n"
-        ".Lgs_exit_%=:\n\t"
-        "s_mov_b64 exec, %[sv]"
+        ".Lgs_exit_%=:"
         : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [T] "+v"(T), [addr] "+v"(slab_addr), [alive] "+s"(alive), [rem] "+s"(left),
           [ev] "=&s"(event), [mk] "=&s"(ev.mk), [m2] "=&s"(ev.m2), [sl] "=&s"(ev.sl), [sv] "=&s"(saved),
           [w] "=&v"(ev.w)
@@ -312,9 +329,47 @@ __device__ __forceinline__ uint32_t blend_pair_loop(uint32_t& slab_addr, uint32_
 #ifndef GS_BLEND_ASM_LOOP_EXACT
 #define GS_BLEND_ASM_LOOP_EXACT 1  // 0 (A/B builds): the compiler's form of the exact mode's pair loop
 #endif
-#ifndef GS_BLEND_EXECZ_BRANCH_EXACT
-#define GS_BLEND_EXECZ_BRANCH_EXACT 1  // the exp section is thirty issue slots here: pairs no pixel keeps branch over it
-#endif
+// Round 6: the single unsigned compare on pn = -power and the unroll by four of the guarded loop (see there); gs_expf_libm takes
+// power = -pn through the conversion's sign modifier.  The exp section is thirty issue slots here: pairs no pixel keeps branch over it.
+#define GS_PAIR_EXACT(J)                                                                                                      \
+        GS_PAIR_HEAD(J)                                                                                                       \
+        "s_cbranch_execz .Lgs_xskip" GS_STR(J) "_%=\n\t"                                                                      \
+        "v_cvt_f64_f32 v[58:59], -v54\n\t"                         /* gs_expf_libm(power):  xd */                             \
+        "v_fma_f64 v[54:55], %[iln], v[58:59], %[shift]\n\t"       /* kd = fma(InvLn2N, xd, SHIFT): k in the low mantissa bits */ \
+        "v_and_b32 v63, 31, v54\n\t"                                                                                          \
+        "v_lshl_add_u32 v63, v63, 3, %[tab]\n\t"                                                                              \
+        "ds_read_b64 v[52:53], v63\n\t"                            /* t = tab[k & 31] */                                      \
+        "v_lshlrev_b32 v56, 15, v54\n\t"                           /* k << 47, its upper word */                              \
+        "v_add_f64 v[54:55], v[54:55], -%[shift]\n\t"              /* kd - SHIFT */                                           \
+        "v_fma_f64 v[58:59], v[58:59], %[iln], -v[54:55]\n\t"      /* r = fma(InvLn2N, xd, -kd) */                            \
+        "v_fma_f64 v[54:55], %[C0], v[58:59], %[C1]\n\t"           /* q = (C0 r + C1) r + C2 */                               \
+        "v_fma_f64 v[54:55], v[54:55], v[58:59], %[C2]\n\t"                                                                   \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                            \
+        "v_add_u32 v53, v56, v53\n\t"                              /* s = t + (k << 47) */                                    \
+        "v_mul_f64 v[58:59], v[58:59], v[52:53]\n\t"               /* r s */                                                  \
+        "v_fma_f64 v[52:53], v[54:55], v[58:59], v[52:53]\n\t"     /* y = fma(q, r s, s) */                                   \
+        "v_cvt_f32_f64 v54, v[52:53]\n\t"                          /* the one rounding to binary32 */                         \
+        "v_mul_f32 v54, v57, v54\n\t"             /* o e */                                                                   \
+        "v_min_f32 v54, 0x3f7d70a4, v54\n\t"      /* alpha = min(0.99, .)             (render.comp:77) */                     \
+        "v_sub_f32 v55, 1.0, v54\n\t"             /* 1 - alpha */                                                             \
+        "v_mul_f32 v55, %[T], v55\n\t"            /* test_T = T (1 - alpha) */                                                \
+        "v_cmp_gt_f32 %[mk], %[k1e4], v55\n\t"    /* test_T < 1e-4: the pixel is done   (render.comp:83; under exec = m2) */  \
+        "s_andn2_b64 exec, exec, %[mk]\n\t"                                                                                   \
+        "v_mul_f32 v60, v60, v54\n\t"             /* color * alpha * T, left to right    (render.comp:87) */                  \
+        "v_mul_f32 v61, v61, v54\n\t"                                                                                         \
+        "v_mul_f32 v62, v62, v54\n\t"                                                                                         \
+        "v_mul_f32 v60, %[T], v60\n\t"                                                                                        \
+        "v_mul_f32 v61, %[T], v61\n\t"                                                                                        \
+        "v_mul_f32 v62, %[T], v62\n\t"                                                                                        \
+        "v_add_f32 %[c0], %[c0], v60\n\t"                                                                                     \
+        "v_add_f32 %[c1], %[c1], v61\n\t"                                                                                     \
+        "v_add_f32 %[c2], %[c2], v62\n\t"                                                                                     \
+        "v_mov_b32 %[T], v55\n\t"                                                                                             \
+        "s_andn2_b64 %[alive], %[alive], %[mk]\n\t"                                                                           \
+        "s_cselect_b32 %[rem], %[rem], 0\n"       /* the quadrant's last pixel is done: this was the last pair */             \
+        ".Lgs_xskip" GS_STR(J) "_%=:\n\t"                                                                                     \
+        "s_mov_b64 exec, %[alive]\n\t"                                                                                        \
+        "s_add_u32 %[rem], %[rem], -1\n\t"        /* carry = there was another pair */
 __device__ __forceinline__ void blend_pair_loop_exact(uint32_t slab_addr, const uint32_t rem, uint64_t& alive, const float fx, const float fy,
                                                       float& T, float& c0, float& c1, float& c2, const uint2* __restrict__ tab) {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;  // gs_expf_libm's constants
@@ -326,64 +381,16 @@ __device__ __forceinline__ void blend_pair_loop_exact(uint32_t slab_addr, const 
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[alive]\n"
-        ".Lgs_xpair_%=:\n\t"
-        "ds_read_b128 v[54:57], %[addr]\n\t"
-        "ds_read_b128 v[58:61], %[addr] offset:1024\n\t"
-        "ds_read_b64 v[62:63], %[addr] offset:2048\n\t"
-        "v_add_u32 %[addr], 16, %[addr]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_sub_f32 v58, v58, %[fx]\n\t"           // dx = u - x
-        "v_sub_f32 v59, v59, %[fy]\n\t"           // dy = v - y
-        "v_mul_f32 v54, v54, v58\n\t"             // c00' dx
-        "v_mul_f32 v56, v56, v59\n\t"             // c11' dy
-        "v_mul_f32 v54, v58, v54\n\t"             // c00' dx dx
-        "v_mul_f32 v56, v59, v56\n\t"             // c11' dy dy
-        "v_mul_f32 v55, v55, v58\n\t"             // c01' dx
-        "v_add_f32 v54, v54, v56\n\t"             // s
-        "v_mul_f32 v55, v55, v59\n\t"             // c01' dx dy
-        "v_add_f32 v54, v55, v54\n\t"             // power = s + c01' dx dy            (render.comp:66)
-        "v_cmpx_ge_f32 vcc, 0, v54\n\t"           // power <= 0 (false for NaN)        (render.comp:68)
-        "v_cmpx_nlt_f32 vcc, v54, v63\n\t"        // !(power < alpha cut)              (render.comp:78, decided on power)
-#if GS_BLEND_EXECZ_BRANCH_EXACT
-        "s_cbranch_execz .Lgs_xskip_%=\n\t"
-#endif
-        "v_cvt_f64_f32 v[58:59], v54\n\t"                          // gs_expf_libm(power):  xd
-        "v_fma_f64 v[54:55], %[iln], v[58:59], %[shift]\n\t"       // kd = fma(InvLn2N, xd, SHIFT): k in the low mantissa bits
-        "v_and_b32 v63, 31, v54\n\t"
-        "v_lshl_add_u32 v63, v63, 3, %[tab]\n\t"
-        "ds_read_b64 v[52:53], v63\n\t"                            // t = tab[k & 31]
-        "v_lshlrev_b32 v56, 15, v54\n\t"                           // k << 47, its upper word
-        "v_add_f64 v[54:55], v[54:55], -%[shift]\n\t"              // kd - SHIFT
-        "v_fma_f64 v[58:59], v[58:59], %[iln], -v[54:55]\n\t"      // r = fma(InvLn2N, xd, -kd)
-        "v_fma_f64 v[54:55], %[C0], v[58:59], %[C1]\n\t"           // q = (C0 r + C1) r + C2
-        "v_fma_f64 v[54:55], v[54:55], v[58:59], %[C2]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_add_u32 v53, v56, v53\n\t"                              // s = t + (k << 47)
-        "v_mul_f64 v[58:59], v[58:59], v[52:53]\n\t"               // r s
-        "v_fma_f64 v[52:53], v[54:55], v[58:59], v[52:53]\n\t"     // y = fma(q, r s, s)
-        "v_cvt_f32_f64 v54, v[52:53]\n\t"                          // the one rounding to binary32
-        "v_mul_f32 v54, v57, v54\n\t"             // o e
-        "v_min_f32 v54, 0x3f7d70a4, v54\n\t"      // alpha = min(0.99, .)             (render.comp:77)
-        "v_sub_f32 v55, 1.0, v54\n\t"             // 1 - alpha
-        "v_mul_f32 v55, %[T], v55\n\t"            // test_T = T (1 - alpha)
-        "v_cmp_gt_f32 %[mk], %[k1e4], v55\n\t"    // test_T < 1e-4: the pixel is done   (render.comp:83; under exec = m2)
-        "s_andn2_b64 exec, exec, %[mk]\n\t"
-        "v_mul_f32 v60, v60, v54\n\t"             // color * alpha * T, left to right    (render.comp:87)
-        "v_mul_f32 v61, v61, v54\n\t"
-        "v_mul_f32 v62, v62, v54\n\t"
-        "v_mul_f32 v60, %[T], v60\n\t"
-        "v_mul_f32 v61, %[T], v61\n\t"
-        "v_mul_f32 v62, %[T], v62\n\t"
-        "v_add_f32 %[c0], %[c0], v60\n\t"
-        "v_add_f32 %[c1], %[c1], v61\n\t"
-        "v_add_f32 %[c2], %[c2], v62\n\t"
-        "v_mov_b32 %[T], v55\n\t"
-        "s_andn2_b64 %[alive], %[alive], %[mk]\n\t"
-        "s_cselect_b32 %[rem], %[rem], 0\n"          // the quadrant's last pixel is done: this was the last pair
-        ".Lgs_xskip_%=:\n\t"
-        "s_mov_b64 exec, %[alive]\n\t"
-        "s_add_u32 %[rem], %[rem], -1\n\t"         // carry = there was another pair
-        "s_cbranch_scc1 .Lgs_xpair_%=\n\t"
+        GS_PAIR_EXACT(0)
+        "s_cbranch_scc0 .Lgs_xdone_%=\n"
+        GS_PAIR_EXACT(1)
+        "s_cbranch_scc0 .Lgs_xdone_%=\n"
+        GS_PAIR_EXACT(2)
+        "s_cbranch_scc0 .Lgs_xdone_%=\n"
+        GS_PAIR_EXACT(3)
+        "v_add_u32 %[addr], 64, %[addr]\n\t"
+        "s_cbranch_scc1 .Lgs_pair0_%=\n"
+        ".Lgs_xdone_%=:\n\t"
         "s_mov_b64 exec, %[sv]"
         : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [T] "+v"(T), [addr] "+v"(slab_addr), [alive] "+s"(alive), [rem] "+s"(left),
           [mk] "=&s"(mk), [sv] "=&s"(saved)
@@ -488,10 +495,10 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
         }
         if constexpr (kAsmLoop) {
             // the kept entries staged in rank order: the hand-written loop walks an address and a count
-            if (keep) {
-                slab[0][rank] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
+            if (keep) {  // (the conic scaled by a power of two, signs as they are: the loop computes pn = -power; ncut = -cut)
+                slab[0][rank] = make_float4(0.5f * cur.co.x, cur.co.y, 0.5f * cur.co.z, cur.co.w);
                 slab[1][rank] = cur.uv;
-                slab[2][rank] = make_float4(cur.bc.x, cut, 0.0f, 0.0f);
+                slab[2][rank] = make_float4(cur.bc.x, -cut, 0.0f, 0.0f);
             }
             __builtin_amdgcn_wave_barrier();
             const uint32_t n_kept = (uint32_t)__popcll(bm0);
@@ -556,10 +563,10 @@ __device__ __forceinline__ bool blend_walk(const uint2 range, const uint32_t* __
             }
         } else if constexpr (kAsmLoopExact) {
             const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm0, 0u));
-            if (keep) {  // staged in rank order, the conic pre-scaled (see below)
-                slab[0][r] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
+            if (keep) {  // staged in rank order, the conic pre-scaled by a power of two (signs as they are: pn = -power), ncut = -cut
+                slab[0][r] = make_float4(0.5f * cur.co.x, cur.co.y, 0.5f * cur.co.z, cur.co.w);
                 slab[1][r] = cur.uv;
-                slab[2][r] = make_float4(cur.bc.x, cut, 0.0f, 0.0f);
+                slab[2][r] = make_float4(cur.bc.x, -cut, 0.0f, 0.0f);
             }
             __builtin_amdgcn_wave_barrier();
             blend_pair_loop_exact((uint32_t)(uintptr_t)&slab[0][0], (uint32_t)__popcll(bm0) - 1u, alive, fx, fy, T, c0, c1, c2, exptab);
