@@ -155,6 +155,7 @@ struct L1Args {
     Counters* counters;
     uint32_t capacity;
     uint32_t nblk;
+    uint64_t* stamps;           // nullable: the frame's timeline (k_l1_hist stamps ST_L1_COUNT, the scatter kernels ST_L1_SCATTER)
 };
 
 __device__ __forceinline__ bool bin_on_screen(const BinGrid& g, uint32_t bin) {

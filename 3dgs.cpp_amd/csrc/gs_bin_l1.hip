@@ -21,6 +21,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_hist(L1Args a) {
     __shared__ uint32_t s_hist[NB];
     __shared__ uint32_t s_vis;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    frame_stamp(a.stamps, ST_L1_COUNT);
     const uint32_t blk = l1_block();
     if (blk >= a.nblk) return;
     uint32_t n = a.n_items ? *a.n_items : a.n_bound;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
     __shared__ uint32_t s_ids[kL1Chunks][WAVE];
     __shared__ uint32_t scratch[8];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    frame_stamp(a.stamps, ST_L1_SCATTER);
     const uint32_t blk = l1_block();
     if (blk >= a.nblk) return;
     {   // bin offsets = exclusive scan of the bin totals (<= 1024 values: every block redoes it, no extra launch)
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
     __shared__ uint32_t s_cur[NB];  // next free slot of this block's run in each bin's list
     __shared__ uint32_t scratch[8];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    frame_stamp(a.stamps, ST_L1_SCATTER);
     const uint32_t blk = l1_block();
     if (blk >= a.nblk) return;
     uint32_t vis_first = 0;
@@ -394,6 +397,7 @@ static L1Args l1_args(const BinLaunch& b) {
     a.capacity = b.cand_capacity;  // (level 1 only ever writes candidates)
     // level-1 blocks: over the N items, or over the slots of the dense lists
     a.nblk = b.vis ? kVisRegions * (b.vis_region_slots / kL1Items) : bin_level1_blocks(b.n_bound);
+    a.stamps = b.stamps;
     return a;
 }
 

@@ -46,6 +46,7 @@ struct BuildArgs {
     SlabDesc* slabs;       // k_bin_slabs -> k_slab_work (level 4)
     uint32_t slab_capacity;
     uint32_t epoch;        // k_bin_queue: see BinLaunch::slab_epoch
+    uint64_t* stamps;      // nullable: the frame's timeline (the level's first kernel stamps ST_L2)
 };
 
 // candidate's tile box clipped to the bin, in bin-local tile coordinates (upper bounds exclusive), packed like l1_item's
@@ -89,6 +90,7 @@ struct BuildLayout {
 
 template <int R2, int THREADS, bool SORT>
 __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
+    frame_stamp(a.stamps, ST_L2);
     BUILD_ROW(blockIdx.x);
     using L = BuildLayout<R2, THREADS, SORT>;
     constexpr int NW = L::NW, MAXC = L::MAXC, SS = L::SS, PER = kBuildSlots / NW;  // PER chunks per wave and round
@@ -460,6 +462,7 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     __shared__ uint32_t q_item, q_planned;              // the claimed item; how many bins are beyond MAXC (they are planned, and first)
 
     BUILD_ROW(MODE == 2 ? 1023u : blockIdx.x);
+    if constexpr (MODE != 2) frame_stamp(a.stamps, ST_L2);  // (k_slab_work is the level's second launch)
     int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;  // (MODE 3 re-derives them per item: see there)
     // one workgroup per ON-SCREEN bin (the grid is bins_x * bins_y: with the padding of the bin grid in it, workgroups
     // that exit at once upset the dispatcher's placement and a few CUs end up with three of the real ones)
@@ -1448,6 +1451,7 @@ void launch_bin_level2(const BinLaunch& b, int level, hipStream_t s) {
     a.slabs = reinterpret_cast<SlabDesc*>(b.slabs);
     a.slab_capacity = b.slab_capacity;
     a.epoch = b.slab_epoch;
+    a.stamps = b.stamps;
     const uint32_t bins = b.bins_x * b.bins_y;  // on-screen bins: the kernels map the block index onto the padded grid
     const bool sort = level < kBinSortLevels;
     if (sort && b.bin_shift <= 3) {  // bins of 4 x 4 or 8 x 8 tiles: the all-in-LDS kernel, sized by the level

@@ -750,7 +750,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                  uint32_t width, uint32_t height, uint32_t tiles_x,
                                                  float4* __restrict__ rgba, uchar4* __restrict__ bgra,
                                                  Counters* __restrict__ counters, Counters* host_counters,
-                                                 const FrameParams* __restrict__ fp, uint32_t* __restrict__ vis_count, uint32_t lockstep) {
+                                                 const FrameParams* __restrict__ fp, uint32_t* __restrict__ vis_count, uint32_t lockstep,
+                                                 uint64_t* __restrict__ stamps) {
+    frame_stamp(stamps, ST_BLEND);
     static_assert(!GUARD || (EXP != 2 && !CONTRACT), "the guard belongs to a fast exp on the uncontracted arithmetic");
     if (fp) {  // graph replay: this frame's targets come from the parameter block
         rgba = reinterpret_cast<float4*>(fp->rgba);
@@ -833,26 +835,43 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 template <int EXP, bool CONTRACT, bool GUARD>
 static void launch_blend_as(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                             uint32_t width, uint32_t height, uint32_t tx, uint32_t ty, float* rgba, uint8_t* bgra,
-                            Counters* counters, Counters* host_counters, const FrameParams* fp, bool lockstep, hipStream_t s) {
+                            Counters* counters, Counters* host_counters, const FrameParams* fp, bool lockstep, uint64_t* stamps, hipStream_t s) {
     hipLaunchKernelGGL((k_blend<EXP, CONTRACT, GUARD>), dim3(tx * ty), dim3(BLOCK), 0, s, reinterpret_cast<const uint2*>(ranges),
                        sorted_gid, tile_order, av.rec, width, height, tx, reinterpret_cast<float4*>(rgba),
-                       reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp, av.vis_count, lockstep ? 1u : 0u);
+                       reinterpret_cast<uchar4*>(bgra), counters, host_counters, fp, av.vis_count, lockstep ? 1u : 0u, stamps);
+}
+
+// The frame's end on its timeline: one wave behind the blend (a dependent dispatch starts when the last workgroup of the kernel before it
+// has retired) stamps the clock and hands the stamps to the host -- pinned memory, visible to it once the frame's completion event has fired.
+__global__ __launch_bounds__(WAVE) void k_frame_end(uint64_t* __restrict__ stamps, uint64_t* host_stamps, const FrameParams* __restrict__ fp) {
+    if (fp) host_stamps = fp->host_stamps;
+    const uint64_t now = wall_clock64();
+    const int t = threadIdx.x;
+    if (t < ST_COUNT) {
+        const uint64_t v = t == ST_END ? now : stamps[t];
+        if (t == ST_END) stamps[t] = now;
+        if (host_stamps) host_stamps[t] = v;
+    }
+}
+void launch_frame_end(uint64_t* stamps, uint64_t* host_stamps, const FrameParams* fp, hipStream_t s) {
+    if (!stamps) return;
+    hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(WAVE), 0, s, stamps, host_stamps, fp);
 }
 
 void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint32_t* tile_order, const AttrView& av,
                   uint32_t width,
                   uint32_t height, float* rgba, uint8_t* bgra, Counters* counters,
-                  Counters* host_counters, int exp_mode, bool contract, const FrameParams* fp, bool lockstep, hipStream_t s) {
+                  Counters* host_counters, int exp_mode, bool contract, const FrameParams* fp, bool lockstep, uint64_t* stamps, hipStream_t s) {
     if (width == 0 || height == 0) return;
     const uint32_t tx = (width + kTile - 1) / kTile, ty = (height + kTile - 1) / kTile;
     if (exp_mode == 3 && !contract)  // the guarded hardware exp; with the contractions on there is nothing to guard: mode 1
         return launch_blend_as<1, false, true>(ranges, sorted_gid, tile_order, av, width, height, tx, ty, rgba, bgra, counters,
-                                               host_counters, fp, lockstep, s);
+                                               host_counters, fp, lockstep, stamps, s);
     if (exp_mode == 3) exp_mode = 1;
 #define GS_BLEND_CASE(E, C)                                                                                              \
     if (exp_mode == E && contract == C)                                                                                  \
         return launch_blend_as<E, C, false>(ranges, sorted_gid, tile_order, av, width, height, tx, ty, rgba, bgra,       \
-                                            counters, host_counters, fp, lockstep, s)
+                                            counters, host_counters, fp, lockstep, stamps, s)
     GS_BLEND_CASE(0, true);
     GS_BLEND_CASE(0, false);
     GS_BLEND_CASE(1, true);

@@ -14,15 +14,19 @@ struct BlendTuner {
     // three frames in flight while the frame rate is 5 % lower).  Per setting: kSkip frames ignored after the switch (frames of the
     // other setting are still in flight beside them), kSamples intervals summed.  Lockstep has to win by 3 %: off is the safe side
     // (-9 % at worst against +25 %).
-    // The windows run OFF (8) - ON (16) - OFF (8): a drift of the clocks over the measurement -- a renderer's first frames run on a chip
+    // The windows run OFF (12) - ON (24) - OFF (12) (round 5: 8 - 16 - 8): a drift of the clocks over the measurement -- a renderer's first frames run on a chip
     // that is still coming up -- then weighs on both settings alike (measured: with a plain off-then-on order config B picked the
     // lockstep it loses 5 % with, three times out of four).  A win for lockstep has to be CONFIRMED by a second pass (won_once).
-    static constexpr int kSkip = 6, kWindow = 8;
+    // Round 6: a renderer's first kHold frames are not measured at all (a fresh process's clocks ramp for ~100 frames -- convexly, which the
+    // symmetric windows do not cancel -- and its first frames may be re-run at another depth-order level), and the windows are 12 - 24 - 12:
+    // one process in four of an A/B had called a 2 % LOSS for lockstep twice in a row inside its first hundred frames
+    // (profiles/r06_blend_pair_loop.txt).
+    static constexpr int kSkip = 6, kWindow = 12, kHold = 40;
     static constexpr uint32_t kPeriod = 4096;       // settled frames between two looks
     int forced = -1;        // -1 automatic, 0 / 1 pinned
     int phase = 0;          // 0: off, 1: on (two windows), 2: off again, 3: settled
     bool choice = false;    // the settled setting
-    uint32_t round = 1, seen = 0, settled_frames = 0;
+    uint32_t round = 1, seen = 0, settled_frames = 0, held = 0;
     double sum[2] = {0, 0};
     int count = 0;
     bool measuring_on() const { return phase == 1; }
@@ -52,6 +56,10 @@ struct BlendTuner {
         if (forced >= 0) return;
         if (phase == 3) {
             if (++settled_frames >= kPeriod) restart();
+            return;
+        }
+        if (held < (uint32_t)kHold) {  // the renderer's first frames: not measured
+            ++held;
             return;
         }
         if (frame_round != round || lockstep != measuring_on()) return;  // a frame of before the switch

@@ -9,6 +9,13 @@
 
 namespace gs {
 
+// the frame's timeline (gs_kernels.h: FrameStamp): a pass's first kernel stamps its start -- thread 0 of workgroup 0, which the
+// dispatcher starts first
+__device__ __forceinline__ void frame_stamp(uint64_t* stamps, int which) {
+    if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[which] = wall_clock64();
+}
+
+
 #define WAVE 64
 #define BLOCK 256
 

@@ -81,6 +81,14 @@ struct Counters {
     // the work queue of k_bin_queue (level 4 in one launch): items handed out so far (bins first, then depth slabs); bins beyond a slab planned so far
     uint32_t q_head, q_bins_done;
 };
+// The frame's timeline, stamped by the kernels themselves (round 6).  Every pass's first kernel writes the constant-rate clock
+// (wall_clock64: s_memrealtime, hipDeviceAttributeWallClockRate kHz) at its start -- thread 0 of workgroup 0 -- and a one-wave kernel
+// behind the blend stamps the frame's end and copies the stamps to pinned host memory.  Round 5 bracketed the passes with hipEvents
+// (the reference's vkCmdWriteTimestamp, Renderer.cpp:484-526): each record is a barrier packet the next dispatch waits for, 4.5 us
+// of idle GPU apiece, 22 us of a 290-us frame rendered alone (profiles/r06_seams.txt); two kernels with nothing between them start
+// back to back.  A span therefore runs from a pass's first kernel's start to the next pass's: the seam belongs to the pass before it.
+enum FrameStamp { ST_PREPROCESS = 0, ST_ORDER = 1, ST_L1_COUNT = 2, ST_L1_SCATTER = 3, ST_L2 = 4, ST_BLEND = 5, ST_END = 6, ST_COUNT = 8 };
+
 // What changes from one frame to the next.  Normally these travel as kernel arguments; when a frame is replayed
 // as a captured HIP graph (gs_set_graph_mode) they are read from this block in device memory instead, which the
 // host refreshes with one small copy ahead of the graph launch -- the graph itself never needs re-recording.
@@ -89,6 +97,7 @@ struct FrameParams {
     float* rgba;
     uint8_t* bgra;
     Counters* host_counters;
+    uint64_t* host_stamps;  // pinned, [ST_COUNT]
 };
 
 // candidates per bin that k_bin_fast orders in LDS at depth-order level 0 .. 3 (8 bytes of LDS each); level 4: k_bin_slabs,
@@ -112,8 +121,11 @@ void launch_blob_checksum(const float* blob, uint64_t floats, uint64_t* out, hip
 void launch_sh_to_half(const float* blob, uint16_t* sh16, uint32_t n, uint32_t stride, hipStream_t s);
 // counters (nullable): the kernel clears the frame's counters, so that a frame needs no memset node.
 // fp (nullable, device memory): read the uniforms / output pointers from it instead of the arguments (graph replay)
+// stamps (nullable, device memory, [ST_COUNT]): the frame's timeline, see FrameStamp
 void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
-                       const FrameParams* fp, hipStream_t s);
+                       const FrameParams* fp, uint64_t* stamps, hipStream_t s);
+// behind the frame's last kernel: stamps[ST_END] = now, the stamps copied to host_stamps (pinned; fp non-null: fp->host_stamps)
+void launch_frame_end(uint64_t* stamps, uint64_t* host_stamps, const FrameParams* fp, hipStream_t s);
 
 // Stable LSD radix pass on (u32 key, u32 value) pairs, 8-bit digit at `shift` (the global depth order).
 //   first != 0: the input is (key = bits(depth[i]), value = i) for every i < n_static with tiles[i] != 0
@@ -135,6 +147,7 @@ struct RadixPass {
     int bits;                 // significant bits in this digit (<= 8)
     int blocks;
     int first;
+    uint64_t* stamps;         // nullable: the pass's first kernel stamps [ST_ORDER] (the caller sets it on the first pass only)
 };
 void launch_radix_pass(const RadixPass& p, hipStream_t s);
 
@@ -166,6 +179,7 @@ struct BinLaunch {
     uint32_t tiles_x, tiles_y, bins_x, bins_y;
     int bin_shift;              // log2 S
     int grid_shift;             // 4 or 5: padded bin id = by << grid_shift | bx
+    uint64_t* stamps;           // nullable: the frame's timeline (FrameStamp); level 1 and level 2 stamp their starts
 };
 // tiles / depth / aabb of the visible Gaussians rebuilt from the dense lists of the frame that just ran (stage taps: k_preprocess
 // writes no planes when level 1 streams the lists); av.vis must be the lists of that frame
@@ -194,6 +208,7 @@ void launch_blend(const uint32_t* ranges, const uint32_t* sorted_gid, const uint
                   bool contract /* the three FMA contractions GLSL permits in render.comp:66,87, or (default) none */,
                   const FrameParams* fp,
                   bool lockstep /* the four waves of a tile take every chunk of its list together (s_barrier): gs_blend.hip */,
+                  uint64_t* stamps /* nullable: [ST_BLEND] = the kernel's start */,
                   hipStream_t s);
 
 }  // namespace gs

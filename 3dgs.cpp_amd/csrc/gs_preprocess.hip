@@ -26,6 +26,7 @@ struct PreUniforms {
     gs_uniforms u;
     Counters* counters;      // nullable
     const FrameParams* fp;   // nullable: the uniforms live there (graph replay)
+    uint64_t* stamps;        // nullable: the frame's timeline
 };
 
 // Wave-private LDS of k_preprocess: the attribute records of a wave's 64 Gaussians on their way to HBM, three planes of
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
     __shared__ float4 s_stage[BLOCK / WAVE][kPreWaveLds];
     const gs_uniforms& u = pu.fp ? pu.fp->u : pu.u;  // uniform either way: scalar loads
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    frame_stamp(pu.stamps, ST_PREPROCESS);
     if (i == 0 && pu.counters) {  // first kernel of the frame: the counters the later kernels accumulate into
         pu.counters->visible = 0;
         pu.counters->instances = 0;
@@ -401,12 +403,13 @@ __global__ __launch_bounds__(BLOCK) void k_preprocess(SceneView sv, PreUniforms 
 }
 
 void launch_preprocess(const SceneView& sv, const gs_uniforms& u, const AttrView& av, Counters* counters,
-                       const FrameParams* fp, hipStream_t s) {
+                       const FrameParams* fp, uint64_t* stamps, hipStream_t s) {
     if (sv.n == 0) return;
     PreUniforms pu;
     pu.u = u;
     pu.counters = counters;
     pu.fp = fp;
+    pu.stamps = stamps;
     hipLaunchKernelGGL(k_preprocess, dim3((sv.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, sv, pu, av);
 }
 }  // namespace gs

@@ -27,6 +27,7 @@ struct RadixArgs {
     int shift;
     uint32_t mask;
     int blocks;
+    uint64_t* stamps;  // nullable: the frame's timeline (the first pass's histogram kernel stamps ST_ORDER)
 };
 
 template <bool FIRST>
@@ -54,6 +55,7 @@ __device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t e, uint3
 template <bool FIRST>
 __global__ __launch_bounds__(BLOCK) void k_radix_hist(RadixArgs a) {
     __shared__ uint32_t hist[256];
+    frame_stamp(a.stamps, ST_ORDER);
     const uint32_t n = radix_count<FIRST>(a);
     const uint32_t ntiles = (n + kSortTileKeys - 1) / kSortTileKeys;
     const uint32_t t0 = (uint32_t)((uint64_t)blockIdx.x * ntiles / a.blocks);
@@ -211,6 +213,7 @@ void launch_radix_pass(const RadixPass& p, hipStream_t s) {
     a.shift = p.shift;
     a.mask = (1u << p.bits) - 1u;
     a.blocks = p.blocks;
+    a.stamps = p.stamps;
     if (p.first) {
         hipLaunchKernelGGL(k_radix_hist<true>, dim3(p.blocks), dim3(BLOCK), 0, s, a);
         hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(BLOCK), 0, s, p.block_hist, p.digit_total, p.blocks);

@@ -57,6 +57,7 @@ struct FrameBuffers {
     DevBuf<uint8_t> slabs;                // depth-slab descriptors (level 4; allocated on first use)
     uint32_t slab_epoch = 0;              // k_bin_queue: one value per launch on these descriptors (BinLaunch::slab_epoch)
     DevBuf<gs::Counters> counters;
+    DevBuf<uint64_t> stamps;              // the frame's timeline, written by its kernels (gs_kernels.h: FrameStamp)
     // HIP-graph replay (gs_set_graph_mode): the frame's fixed-shape launches captured once per configuration
     DevBuf<gs::FrameParams> params;
     // ... one per setting of the blend's lockstep: the tuner flips it several times per measurement, and re-capturing the frame on every
@@ -103,6 +104,8 @@ struct FrameBuffers {
         l1_hist.alloc(1025 * static_cast<size_t>(gs::bin_level1_columns(static_cast<uint32_t>(n))));  // + the row of visible counts
         bin_count.alloc(1024);
         counters.alloc(1);
+        stamps.alloc(gs::ST_COUNT);
+        HIP_CHECK(hipMemset(stamps.p, 0, gs::ST_COUNT * sizeof(uint64_t)));
         params.alloc(1);
         set_capacity(capacity);
         set_cand_capacity(cand_capacity);
@@ -152,9 +155,9 @@ struct FrameSlot {
     gs_uniforms u{};
     float* rgba = nullptr;
     uint8_t* bgra = nullptr;
-    hipEvent_t ev[9] = {};
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;           // the frame's one event: completion (round 5 bracketed every pass with one: 4.5 us of idle GPU each)
     gs::Counters* h_counters = nullptr;  // pinned
+    uint64_t* h_stamps = nullptr;        // pinned [ST_COUNT]: the frame's timeline, written by its kernels and copied here by k_frame_end
     gs::FrameParams* h_params = nullptr;  // pinned staging of the frame's parameter block (graph replay)
     bool timed = false;
     int level = 0;  // the depth-order level this frame ran at (gs_renderer::level)
@@ -171,7 +174,8 @@ struct gs_renderer {
     static constexpr int kSlots = 2 * kMaxInFlight;
 
     gs_scene* scene = nullptr;
-    bool timing = true;
+    bool timing = true;          // gs_set_timing: per-pass spans in the statistics (free since round 6: the kernels stamp them)
+    double tick_ms = 1e-5;       // one tick of the kernels' clock in ms (100 MHz unless the device says otherwise)
 
     FrameBuffers sets[kMaxInFlight];
     int num_sets = 1;
@@ -266,10 +270,9 @@ struct gs_renderer {
 
     ~gs_renderer() {
         for (auto& sl : slots) {
-            for (auto& e : sl.ev)
-                if (e) (void)hipEventDestroy(e);
             if (sl.done) (void)hipEventDestroy(sl.done);
             if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+            if (sl.h_stamps) (void)hipHostFree(sl.h_stamps);
             if (sl.h_params) (void)hipHostFree(sl.h_params);
         }
     }
@@ -288,12 +291,16 @@ struct gs_renderer {
     void init() {
         if (const char* e = std::getenv("GS_BLEND_LOCKSTEP")) tuners.pin(std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0));
         HIP_CHECK(hipSetDevice(scene->device));
+        {   // the clock the kernels stamp the frame's timeline with (wall_clock64): constant rate, in kHz
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, scene->device) == hipSuccess && khz > 0) tick_ms = 1.0 / khz;
+        }
         HIP_CHECK(gs::bin_prepare_device());
         if (std::getenv("GS_DEBUG_OCCUPANCY")) gs::bin_debug_occupancy();
         for (auto& sl : slots) {
-            // span timestamps only: no system-scope fence (L2 write-back) between the passes; `done` keeps the fence
-            for (auto& e : sl.ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
             HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_stamps), gs::ST_COUNT * sizeof(uint64_t), hipHostMallocDefault));
+            std::memset(sl.h_stamps, 0, gs::ST_COUNT * sizeof(uint64_t));
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(gs::Counters), hipHostMallocDefault));
             *sl.h_counters = gs::Counters{};
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_params), sizeof(gs::FrameParams), hipHostMallocDefault));
@@ -409,7 +416,6 @@ struct gs_renderer {
         FrameSlot& sl = slots[frames_enqueued % kSlots];
         FrameBuffers& fb = sets[frames_enqueued % num_sets];
         hipStream_t stream = fb.stream;
-        hipEvent_t* ev = sl.ev;
         const uint32_t n = static_cast<uint32_t>(scene->n);
         const uint32_t tx = (u.width + gs::kTile - 1) / gs::kTile, ty = (u.height + gs::kTile - 1) / gs::kTile;
         if (tx > 65535 || ty > 65535) throw Error(GS_ERR_INVALID, "resolution too large (tile box is 16-bit)");
@@ -464,9 +470,9 @@ struct gs_renderer {
         }
         if (fb.blend_stream && fb.blend_recorded) HIP_CHECK(hipStreamWaitEvent(stream, fb.blend_done, 0));  // the set's previous blend
         // the frame's launches; `fp` non-null = replayable form (per-frame values read from fb.params), no span events
-        auto passes = [&](const gs::FrameParams* fp, bool spans, hipStream_t bstream) {
-            gs::launch_preprocess(sv, u, av, cnt, fp, stream);
-            if (spans) HIP_CHECK(hipEventRecord(ev[1], stream));
+        uint64_t* const stamps = fb.stamps.p;
+        auto passes = [&](const gs::FrameParams* fp, hipStream_t bstream) {
+            gs::launch_preprocess(sv, u, av, cnt, fp, stamps, stream);
             lap(3);
             if (!bin_local && n != 0) {
                 // ---- global depth order of the visible Gaussians: 4 x 8-bit stable passes on bits(depth) ----
@@ -490,12 +496,12 @@ struct gs_renderer {
                     p.bits = 8;
                     p.blocks = blocks;
                     p.first = pass == 0;
+                    p.stamps = pass == 0 ? stamps : nullptr;
                     gs::launch_radix_pass(p, stream);
                     kin = fb.dkeys[dst].p;
                     vin = fb.dvals[dst].p;
                 }
             }
-            if (spans) HIP_CHECK(hipEventRecord(ev[2], stream));
             lap(4);
             if (n != 0) {
                 gs::BinLaunch b{};
@@ -531,19 +537,14 @@ struct gs_renderer {
                 b.bins_y = geo.bins_y;
                 b.bin_shift = geo.bin_shift;
                 b.grid_shift = geo.grid_shift;
+                b.stamps = stamps;
                 // ---- level 1: which Gaussian touches which bin (count + scan, then the per-bin candidate lists) ----
                 gs::launch_bin_level1_count(b, stream);
-                if (spans) HIP_CHECK(hipEventRecord(ev[3], stream));
                 gs::launch_bin_level1_scatter(b, l1_any_order, stream);
-                if (spans) HIP_CHECK(hipEventRecord(ev[4], stream));
                 lap(5);
                 // ---- level 2: order inside the bin (bin-local path), tile ranges, per-tile lists ----
                 gs::launch_bin_level2(b, lv, stream);
-            } else if (spans) {
-                HIP_CHECK(hipEventRecord(ev[3], stream));
-                HIP_CHECK(hipEventRecord(ev[4], stream));
             }
-            if (spans) HIP_CHECK(hipEventRecord(ev[5], stream));
             lap(6);
             // ---- blend ----
             if (bstream != stream) {
@@ -551,7 +552,8 @@ struct gs_renderer {
                 HIP_CHECK(hipStreamWaitEvent(bstream, fb.prep_done, 0));
             }
             gs::launch_blend(fb.ranges.p, fb.sorted.p, tile_order.p, av, u.width, u.height, d_rgba, d_bgra, cnt,
-                             fused_counters ? sl.h_counters : nullptr, blend_exp_mode(), contract, fp, lockstep, bstream);
+                             fused_counters ? sl.h_counters : nullptr, blend_exp_mode(), contract, fp, lockstep, stamps, bstream);
+            gs::launch_frame_end(stamps, sl.h_stamps, fp, bstream);
             lap(7);
         };
         depth_order = bin_local ? nullptr : fb.dvals[1].p;
@@ -559,7 +561,7 @@ struct gs_renderer {
         hipStream_t bstream = fb.blend_stream ? fb.blend_stream : stream;
         const bool replay = graph_mode && fused_counters && !fb.blend_stream;
         if (replay) {
-            *sl.h_params = gs::FrameParams{u, d_rgba, d_bgra, sl.h_counters};
+            *sl.h_params = gs::FrameParams{u, d_rgba, d_bgra, sl.h_counters, sl.h_stamps};
             HIP_CHECK(hipMemcpyAsync(fb.params.p, sl.h_params, sizeof(gs::FrameParams), hipMemcpyHostToDevice, stream));
             FrameBuffers::GraphKey key;
             key.level = lv;
@@ -580,7 +582,7 @@ struct gs_renderer {
                 hipGraph_t graph = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 try {
-                    passes(fb.params.p, false, stream);
+                    passes(fb.params.p, stream);
                 } catch (...) {
                     (void)hipStreamEndCapture(stream, &graph);
                     if (graph) (void)hipGraphDestroy(graph);
@@ -592,13 +594,10 @@ struct gs_renderer {
                 HIP_CHECK(e);
                 fb.graph_keys[gi] = key;
             }
-            HIP_CHECK(hipEventRecord(ev[0], stream));
             HIP_CHECK(hipGraphLaunch(fb.graph_execs[gi], stream));
         } else {
-            HIP_CHECK(hipEventRecord(ev[0], stream));
-            passes(nullptr, timing, bstream);
+            passes(nullptr, bstream);
         }
-        HIP_CHECK(hipEventRecord(ev[7], bstream));
         if (!fused_counters) HIP_CHECK(hipMemcpyAsync(sl.h_counters, cnt, sizeof(gs::Counters), hipMemcpyDeviceToHost, bstream));
         HIP_CHECK(hipEventRecord(sl.done, bstream));
         if (fb.blend_stream) {
@@ -615,7 +614,7 @@ struct gs_renderer {
         sl.u = u;
         sl.rgba = d_rgba;
         sl.bgra = d_bgra;
-        sl.timed = timing && !replay;
+        sl.timed = fused_counters;  // (a frame without Gaussians or pixels launches nothing that stamps)
         ++frames_enqueued;
         ++pending;
         lap(9);
@@ -750,23 +749,26 @@ struct gs_renderer {
         st.sort_level = static_cast<uint32_t>(sl.level);
         st.bin_tiles = 1u << sl.bin_shift;
         st.instance_capacity = capacity;
+        // The frame's timeline as its kernels stamped it (gs_kernels.h: FrameStamp), in ticks of the device's constant-rate clock: a
+        // span runs from the start of a pass's first kernel to the start of the next pass's -- the seam behind a pass belongs to it.
+        const uint64_t* const ts = sl.h_stamps;
         auto span = [&](int a, int b) {
-            float ms = 0.0f;
-            HIP_CHECK(hipEventElapsedTime(&ms, sl.ev[a], sl.ev[b]));
-            return ms;
+            const int64_t d = static_cast<int64_t>(ts[b] - ts[a]);
+            return d > 0 ? static_cast<float>(static_cast<double>(d) * tick_ms) : 0.0f;
         };
-        st.ms_total = span(0, 7);
-        if (sl.timed) {
+        if (sl.timed) st.ms_total = span(gs::ST_PREPROCESS, gs::ST_END);
+        if (sl.timed && timing) {
             // The reference's six span names (Renderer.cpp:484-526, 580-699).  prefix_sum = the level-1 count + scan,
             // preprocess_sort = the level-1 scatter (what lands where), sort = the global depth order (when taken) +
             // k_bin_build.  k_bin_build also produces the tile ranges: tile_boundary.comp's work has no kernel of
             // its own any more, so that span is 0 by construction.
-            st.ms_preprocess = span(0, 1);
-            st.ms_prefix_sum = span(2, 3);
-            st.ms_preprocess_sort = span(3, 4);
-            st.ms_sort = span(1, 2) + span(4, 5);
+            const bool global = sl.level >= kGlobalLevel;  // (only then is ST_ORDER this frame's)
+            st.ms_preprocess = span(gs::ST_PREPROCESS, global ? gs::ST_ORDER : gs::ST_L1_COUNT);
+            st.ms_prefix_sum = span(gs::ST_L1_COUNT, gs::ST_L1_SCATTER);
+            st.ms_preprocess_sort = span(gs::ST_L1_SCATTER, gs::ST_L2);
+            st.ms_sort = (global ? span(gs::ST_ORDER, gs::ST_L1_COUNT) : 0.0f) + span(gs::ST_L2, gs::ST_BLEND);
             st.ms_tile_boundary = 0.0f;
-            st.ms_render = span(5, 7);
+            st.ms_render = span(gs::ST_BLEND, gs::ST_END);
         }
         st.retries = retries;
         last = st;
@@ -779,8 +781,10 @@ struct gs_renderer {
         {   // frames on different streams may finish out of order: measure against the latest completion so far
             const uint64_t idx = frames_enqueued - pending;  // this frame
             if (prev_retired) {
-                float dt = 0.0f;
-                if (hipEventElapsedTime(&dt, slots[latest_done % kSlots].ev[7], sl.ev[7]) == hipSuccess) {
+                // (the frames' END stamps: one clock for every stream)
+                const int64_t dticks = static_cast<int64_t>(ts[gs::ST_END] - slots[latest_done % kSlots].h_stamps[gs::ST_END]);
+                const float dt = dticks > 0 ? static_cast<float>(static_cast<double>(dticks) * tick_ms) : 0.0f;
+                {
                     if (intervals.size() >= kIntervalRing) intervals.erase(intervals.begin(), intervals.begin() + kIntervalRing / 2);
                     intervals.push_back(dt > 0.0f ? dt : 0.0f);  // 0: it had already finished when its predecessor did
                     // the blend tuner compares completion rates (or, for a host-paced consumer, the frames' own spans: BlendTuner::cost)

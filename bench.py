@@ -523,7 +523,7 @@ def other_configs(pkg, torch, dev, device, args, budget_s):
             rend.set_exp_mode(MODES[mode][0])
             rend.set_blend_contraction(MODES[mode][1])
             rend.set_frames_in_flight(fif)
-            for i in range(max(140, frames // 2)):  # warm: depth-order level settled, the blend's lockstep measured and chosen (<= ~125 frames)
+            for i in range(max(200, frames // 2)):  # warm: depth-order level settled, the blend's lockstep measured and chosen (<= ~180 frames)
                 rend.render(u, outs[i % fif].data_ptr(), 0)
             rend.synchronize()
             best = []

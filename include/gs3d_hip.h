@@ -158,7 +158,7 @@ void gs_scene_destroy(gs_scene* s);
 /* ---- renderer: Renderer --------------------------------------------------- */
 
 /* Renderer::initialize (Renderer.cpp:19-31) minus Vulkan/swapchain/GUI: stream,
- * per-frame buffers, timing events.  The scene must outlive the renderer. */
+ * per-frame buffers, the completion events.  The scene must outlive the renderer. */
 int gs_renderer_create(gs_scene* scene, gs_renderer** out);
 void gs_renderer_destroy(gs_renderer* r);
 
@@ -178,7 +178,10 @@ int gs_render(gs_renderer* r, const gs_uniforms* u, float* d_rgba, uint8_t* d_bg
 int gs_render_host(gs_renderer* r, const gs_uniforms* u, float* h_rgba, uint8_t* h_bgra);
 
 int gs_synchronize(gs_renderer* r);
-/* Enable/disable the six hipEvent spans (off: one total span only). */
+/* Enable/disable the six per-pass spans of gs_frame_stats (off: the total only).  The reference writes timestamps around every
+ * pass (Renderer.cpp:484-526, 580-699; QueryManager.cpp:22-41); here the kernels stamp the device's constant-rate clock at
+ * their start themselves, so the spans cost nothing (round 5 recorded a hipEvent per pass: 4.5 us of idle GPU each).  A
+ * span runs from the start of a pass's first kernel to the start of the next pass's. */
 int gs_set_timing(gs_renderer* r, int enabled);
 /* Frames that may be queued on the stream before gs_render blocks (1..8, default 1 like
  * FRAMES_IN_FLIGHT, VulkanContext.h:6).  With k > 1 the renderer keeps k sets of per-frame buffers

@@ -46,16 +46,18 @@ def test_picks_the_faster_schedule(sim, in_flight):
 
 
 def test_a_measurement_costs_few_frames(sim):
-    # three windows (8 + 16 + 8 frames) + 6 skipped after each switch + what is in flight: the wrong setting runs for at most
-    # 22 + in-flight frames of a renderer's first ~55
+    # the renderer's first 40 frames are not measured (the clocks of a fresh process ramp); then three windows (12 + 24 + 12 frames)
+    # + 6 skipped after each switch + what is in flight: the wrong setting runs for at most 30 + in-flight frames of a renderer's
+    # first ~110
+    hold, one_pass = 40, 3 * 6 + 48
     for in_flight in (1, 3):
         choice, at, on = run(sim, 0.22, 0.24, in_flight=in_flight)
-        assert choice == 0 and 0 < at <= 50 + 3 * in_flight
-        assert on <= 22 + in_flight
+        assert choice == 0 and hold < at <= hold + one_pass + 3 * in_flight
+        assert on <= 30 + in_flight
         # a win for lockstep is confirmed by a second pass before it is taken: twice the frames, half of them already in lockstep
         choice, at, on = run(sim, 0.80, 0.60, in_flight=in_flight)
-        assert choice == 1 and 50 < at <= 2 * (50 + 3 * in_flight)
-        assert 2 * 22 <= on <= 2 * (22 + in_flight)
+        assert choice == 1 and hold + one_pass < at <= hold + 2 * (one_pass + 3 * in_flight)
+        assert 2 * 30 <= on <= 2 * (30 + in_flight)
 
 
 def test_off_is_kept_unless_lockstep_wins_by_three_percent(sim):
@@ -90,7 +92,7 @@ def test_it_looks_again_after_4096_settled_frames(sim):
     # lockstep first loses, then (the camera moved into a denser part of the scene) wins
     second = sim.tuner_relook(1.0, 1.1, 0.7, 3, C.byref(first), C.byref(relook))
     assert first.value == 0 and second == 1
-    assert 4096 <= relook.value <= 4096 + 64
+    assert 4096 <= relook.value <= 4096 + 40 + 66 + 16  # (counted from the first frame: the hold and the first pass come before the period)
 
 
 def test_frames_of_an_earlier_round_are_not_counted(sim):
@@ -114,7 +116,7 @@ def test_alternating_frame_shapes_each_settle(sim):
     used = C.c_int()
     for in_flight in (1, 3):
         got = sim.tuner_bank_alternating(0.80, 0.60, 0.10, 0.11, in_flight, 1000, C.byref(used))
-        assert got == 1 and 0 < used.value <= 2 * 2 * (50 + 3 * in_flight) + 8   # A: lockstep (two passes), B: off
+        assert got == 1 and 0 < used.value <= 2 * (40 + 2 * (66 + 3 * in_flight)) + 8   # A: lockstep (two passes), B: off
         got = sim.tuner_bank_alternating(0.22, 0.24, 0.30, 0.20, in_flight, 1000, C.byref(used))
         assert got == 2
 

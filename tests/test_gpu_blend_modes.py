@@ -118,7 +118,7 @@ def test_blend_lockstep_changes_no_pixel_and_the_tuner_settles(pkg, gpu):
     rend.set_frames_in_flight(3)
     assert rend.blend_lockstep()[1] is False
     seen = set()
-    for k in range(220):  # (a win for lockstep takes two passes of ~55 frames)
+    for k in range(320):  # (40 frames of hold, then a win for lockstep takes two passes of ~70 frames)
         img = rend.render_host(u)[0]
         assert np.array_equal(img.view(np.uint32), images[(0, 3)].view(np.uint32)), k
         seen.add(rend.blend_lockstep()[0])

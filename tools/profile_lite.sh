@@ -16,7 +16,7 @@ python -c "import __graft_entry__ as e; print(e.load_package().binding.library_s
 cd /tmp && export TMPDIR=/tmp
 # counter passes: enough untimed frames ahead of the three counted ones that the renderer has settled -- the depth-order level (config C
 # refines its bins and steps down to k_bin_fast<12> on the first clean frame), and the blend's lockstep, which it measures over 55 to 125 frames
-PW=${GS_PROFILE_WARM:-140}
+PW=${GS_PROFILE_WARM:-200}
 PMC="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"
 for W in $WL; do
   case $W in

@@ -139,7 +139,7 @@ for wl in [d for d in ("B", "C", "T", "E") if os.path.isdir(os.path.join(src, d)
 
 if workloads:
     with open(os.path.join(dst, tag + "_pmc_counters.txt"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --pmc <counters> -- " + CMD + " --fif 1 --frames 3 --warm 140  (MI355X; lockstep pinned to the renderer's measured choice); three separate runs per workload:\n"
+        f.write("# rocprofv3 --kernel-trace --pmc <counters> -- " + CMD + " --fif 1 --frames 3 --warm 200  (MI355X; lockstep pinned to the renderer's measured choice); three separate runs per workload:\n"
                 "#   SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY | FETCH_SIZE | WRITE_SIZE\n"
                 "# medians over the dispatches of a run.  FETCH_SIZE / WRITE_SIZE in KB.  SQ_*_CYCLES are quad-cycles; SQ_BUSY_CYCLES is summed over 32 shader engines.\n")
         f.write("\n".join(pmc_txt) + "\n")
