@@ -21,8 +21,13 @@ namespace gs {
 
 // ---------------------------------------------------------------------------------------
 // blend.  One wave per 8x8 pixel quadrant of a 16x16 tile (4 waves = one workgroup per tile), and the
-// four waves are fully independent: no workgroup barrier anywhere, so a quadrant whose pixels have
-// saturated retires at once and a slow quadrant never stalls its neighbours.
+// four waves share nothing: their LDS slabs, tables and lists are wave-private, so a quadrant whose pixels have
+// saturated retires at once.  The ONE workgroup barrier is optional and sits at the top of the chunk loop
+// (`lockstep`, blend_walk): the waves of a tile that are still in that loop take every chunk together.  A wave leaves
+// the loop for good when its quadrant has saturated or the guard abandons it, and s_barrier counts only the waves
+// of the workgroup that have not ENDED -- so: NO barrier may follow the chunk loop (the exact re-render of an
+// abandoned quadrant, the pixel stores): a wave waiting there would wait for siblings that wait at the loop's top
+// for it.  tests/test_gpu_guard.py::test_lockstep_with_quadrants_that_end_early_abandon_and_walk_on mixes the three.
 //
 // Each wave walks its tile's depth-sorted list in chunks of 64 entries: lane l fetches entry l's record
 // (one 64-byte line, gathered through the sorted Gaussian id; the next chunk is prefetched while the current one
@@ -759,9 +764,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         bgra = reinterpret_cast<uchar4*>(fp->bgra);
         host_counters = fp->host_counters;
     }
-    // wave-private slabs (no cross-wave sharing, no barriers)
+    // wave-private slabs (no cross-wave sharing; the only workgroup barrier is the lockstep one at the top of blend_walk's chunk loop)
     __shared__ float4 s_rec[4][3][WAVE];
-    __shared__ uint2 s_exptab[(EXP == 2 || GUARD) ? 4 : 1][32];  // wave-private copies of kExpfTab (no workgroup barrier in this kernel)
+    __shared__ uint2 s_exptab[(EXP == 2 || GUARD) ? 4 : 1][32];  // wave-private copies of kExpfTab: filled and read by their own wave, wave_barrier only
     __shared__ uint32_t s_klist[GUARD ? 4 : 1][GUARD ? kGuardList : 1];  // GUARD: each wave's list of kept entries (resolve_break)
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
@@ -813,11 +818,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 table_ready = true;
             }
             if (lane == 0) atomicAdd(&counters->blend_redo, 1u);
-            // (alone: the other waves of the tile are in their own walks, or done; no barriers here)
+            // (alone: the other waves of the tile are in their own walks, or done.  lockstep = false HERE, always: this wave has left the
+            // lockstepped loop, its siblings may still be in it -- a barrier in this walk would deadlock the tile)
             (void)blend_walk<2, false, false>(range, sorted_gid, rec, s_rec[w], s_exptab[w], nullptr, lane, fx, fy, rx0, ry0, alive, c0, c1, c2,
                                               unused, table_ready, false);
         }
     }
+    // (no __syncthreads / s_barrier from here to the end: see the header)
     if (inside) {
         const size_t p = (size_t)py * width + px;
         if (rgba) rgba[p] = make_float4(c0, c1, c2, 1.0f);  // :98

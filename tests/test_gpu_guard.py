@@ -220,3 +220,81 @@ def test_guard_state_survives_mode_switches_and_frames_in_flight(pkg, oracle, gp
     np.testing.assert_array_equal(c3.view(np.uint32), c1.view(np.uint32))
     rend.close()
     scene.close()
+
+
+def test_lockstep_with_quadrants_that_end_early_abandon_and_walk_on(pkg, oracle, gpu):
+    """The lockstep barrier (gs_blend.hip: one s_barrier per chunk, the tile's four waves together) sits in a loop that each wave of a
+    tile may leave at a different chunk: a quadrant whose pixels have all saturated stops, a quadrant the guard abandons re-renders
+    itself exactly while its siblings walk on (round-5 advisor finding: correctness rests on ended waves no longer counting for the
+    barrier).  One scene with all three in the same tiles: the adversarial stack (guard replays and abandoned quadrants, 64 layers =
+    254 layers = four or five chunks with the plugs' entries) and ~60 opaque plugs of ten tight layers each in front of it, scattered so that some
+    quadrants are covered whole (dead after a few entries), some in part, some not at all.  Lockstep pinned ON must give the frames
+    of lockstep OFF bit for bit in both modes, the exact mode the reference's frame, the default mode its decisions (<= 1e-5)."""
+    w = h = 512
+    rng = np.random.default_rng(77)
+    stack = adversarial_vertices(shift=(0.05, -0.1), strong=0.9006, weak_layers=250, seed=3)
+    f = w / (2 * np.tan(np.radians(45.0) / 2))
+    plugs = []
+    for _ in range(60):
+        cx, cy = rng.uniform(-1.9, 1.9, 2)
+        sigma_px = rng.uniform(5.0, 14.0)
+        for layer in range(10):
+            d = 4.0 + 0.01 * layer + rng.uniform(0, 0.005)
+            plugs.append((cx * d / 4.0, cy * d / 4.0, -d, sigma_px * d / f))
+    plugs = np.array(plugs)
+    pv = _vertices(plugs[:, :3], np.repeat(plugs[:, 3:4], 3, axis=1), np.full(len(plugs), 0.999, np.float32), rng.uniform(0.1, 0.9, (len(plugs), 3)))
+    verts = np.concatenate([pv, stack])
+    u_ref, ref = _reference(oracle, verts, w, h)
+    scene = pkg.Scene.from_vertices(verts, device=0)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    frames = {}
+    for lockstep in (0, 1):
+        rend = pkg.Renderer(scene)
+        rend.set_blend_lockstep(lockstep)
+        rend.set_exp_mode(2)
+        frames[(lockstep, 2)] = rend.render_host(u)[0]
+        if lockstep == 0:
+            compare_stages(pkg, rend, u, ref)
+        worst, redo, resolved = assert_guarded_close(rend, u, ref["image"], label=f"plugs + stack, lockstep {lockstep}: guarded blend")
+        frames[(lockstep, 3)] = rend.render_host(u)[0]
+        print(f"lockstep {lockstep}: guarded max|d| {worst:.3g}, {resolved} decisions resolved exactly, {redo} quadrants re-rendered")
+        assert resolved > 0 and redo > 0, "the scene must make the guard replay AND abandon (else it does not test the mix)"
+        rend.close()
+    assert_images_identical(frames[(0, 2)], ref["image"], label="exp mode 2, lockstep off")
+    for mode in (2, 3):
+        np.testing.assert_array_equal(frames[(0, mode)].view(np.uint32), frames[(1, mode)].view(np.uint32))
+    # ... and the premise itself: tiles exist whose four waves leave the chunk loop at different chunks
+    end_chunk = _quadrant_end_chunks(ref, w, h)
+    per_tile = end_chunk.reshape(h // 16, 2, w // 16, 2).transpose(0, 2, 1, 3).reshape(-1, 4)
+    mixed = int((per_tile.max(axis=1) > per_tile.min(axis=1)).sum())
+    print(f"tiles whose quadrants end in different chunks: {mixed} of {len(per_tile)}; end chunks {np.bincount(end_chunk.ravel())}")
+    assert mixed >= 20, "too few tiles mix early-ending and long-walking quadrants"
+    scene.close()
+
+
+def _quadrant_end_chunks(ref, w, h):
+    """float64 re-trace (per tile list): for every 8 x 8 quadrant the 64-entry chunk of its tile's list in which its last pixel breaks
+    (render.comp:83), or the list's last chunk if one never does -- where the quadrant's wave leaves the blend's chunk loop."""
+    attr, bounds, payload = ref["attr"], ref["boundaries"], ref["sorted_payload"]
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    out = np.zeros((2 * ty, 2 * tx), np.int64)
+    for t in range(tx * ty):
+        ids = payload[bounds[2 * t]:bounds[2 * t + 1]]
+        n = len(ids)
+        if n == 0:
+            continue
+        x0, y0 = (t % tx) * 16, (t // tx) * 16
+        ys, xs = np.mgrid[y0:y0 + 16, x0:x0 + 16].astype(np.float64)
+        co = attr["conic_opacity"][ids].astype(np.float64)
+        uv = attr["uv"][ids].astype(np.float64)
+        dx = uv[:, 0][:, None, None] - xs[None]
+        dy = uv[:, 1][:, None, None] - ys[None]
+        power = -0.5 * (co[:, 0][:, None, None] * dx * dx + co[:, 2][:, None, None] * dy * dy) - co[:, 1][:, None, None] * dx * dy
+        alpha = np.minimum(0.99, co[:, 3][:, None, None] * np.exp(np.minimum(power, 0)))
+        kept = (power <= 0) & (alpha >= 1 / 255)
+        T = np.cumprod(np.where(kept, 1 - alpha, 1.0), axis=0)
+        broke = kept & (T < 1e-4)
+        first = np.where(broke.any(axis=0), broke.argmax(axis=0), n - 1)   # [16, 16] entry at which the pixel stops
+        q = first.reshape(2, 8, 2, 8).max(axis=(1, 3))
+        out[2 * (t // tx):2 * (t // tx) + 2, 2 * (t % tx):2 * (t % tx) + 2] = q // 64
+    return out
