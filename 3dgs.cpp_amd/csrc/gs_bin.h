@@ -138,6 +138,10 @@ struct BinGrid {
     int grid_shift;             // log2 GW: padded bin id = by << grid_shift | bx
 };
 
+// bin_count[0 .. 1024): candidates per (padded) bin, by k_l1_scan; bin_count[kBinOffsets + b]: the exclusive prefix of those, by block 0 of
+// the scatter kernels (round 6: every level-2 workgroup used to redo the 1024-wide scan -- two block scans, 1.7 us of a bin's 35)
+constexpr uint32_t kBinOffsets = 1024;
+
 struct L1Args {
     BinGrid g;
     const uint32_t* order;      // null: item p is Gaussian p; else item p is Gaussian order[p] (depth order)

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter(L1Args a) {
         for (int k = 0; k < NB / BLOCK; ++k) {
             const uint32_t b = tid * (NB / BLOCK) + k;
             s_start[b] = off + (bin_on_screen(a.g, b) ? a.hist[(size_t)b * a.nblk + blk] : 0u);
+            if (blk == 0) a.bin_count[kBinOffsets + b] = off;  // where bin b's run starts: level 2 reads it instead of redoing this scan per bin
             off += c[k];
             if (blk == 0 && c[k]) atomicMax(&a.counters->max_bin, c[k]);  // the fullest bin
         }
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(BLOCK) void k_l1_scatter_any_order(L1Args a) {
         for (int k = 0; k < NB / BLOCK; ++k) {
             const uint32_t b = tid * (NB / BLOCK) + k;
             s_cur[b] = off + (bin_on_screen(a.g, b) ? a.hist[(size_t)b * a.nblk + blk] : 0u);
+            if (blk == 0) a.bin_count[kBinOffsets + b] = off;  // where bin b's run starts: level 2 reads it instead of redoing this scan per bin
             off += c[k];
             if (blk == 0 && c[k]) atomicMax(&a.counters->max_bin, c[k]);  // the fullest bin
         }

@@ -109,20 +109,9 @@ __global__ __launch_bounds__(THREADS) void k_bin_build(BuildArgs a) {
     const uint32_t bin = ((blockIdx.x / a.g.bins_x) << a.g.grid_shift) | (blockIdx.x % a.g.bins_x);  // on-screen bins only
     BUILD_T(0);
     uint32_t c, off;
-    {   // this bin's count and offset (exclusive scan over the <= 1024 bins of the padded grid)
-        const uint32_t nb = 1u << (2 * a.g.grid_shift);
-        uint32_t mine = 0, before = 0;
-        for (uint32_t b = tid; b < nb; b += THREADS) {
-            const uint32_t v = a.bin_count[b];
-            if (b < bin) before += v;
-            if (b == bin) mine = v;
-        }
-        uint32_t tot_before, tot_mine;
-        block_excl_scan<THREADS>(before, scratch, &tot_before);
-        block_excl_scan<THREADS>(mine, scratch, &tot_mine);
-        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot_mine);   // block-uniform: keep them scalar
-        off = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot_before);
-    }
+    // this bin's count and offset (k_l1_scan, the scatter's block 0); block-uniform: scalar loads
+    c = a.bin_count[bin];
+    off = a.bin_count[kBinOffsets + bin];
     if ((uint64_t)off + c > a.cand_capacity) c = 0;  // candidate overflow (flagged by k_l1_scatter): the frame is re-run
     if (SORT && c > (uint32_t)MAXC) {
         if (tid == 0) atomicOr(&a.counters->overflow, 2u);
@@ -471,17 +460,11 @@ __device__ __forceinline__ void bin_fast_body(const BuildArgs& a) {
     bool slab_item = MODE == 2;  // MODE 3: the item at hand is a depth slab (block-uniform)
     BUILD_T(0);
     uint32_t c_total = 0, off = 0;
-    auto bin_extent = [&]() {  // this bin's count and offset (the padded grid has <= 1024 = THREADS bins)
-        const uint32_t nb = 1u << (2 * a.g.grid_shift);
-        const uint32_t v = (uint32_t)tid < nb ? a.bin_count[tid] : 0u;
-        uint32_t tb, tm;
-        block_excl_scan<THREADS>((uint32_t)tid < bin ? v : 0u, scratch, &tb);
-        block_excl_scan<THREADS>((uint32_t)tid == bin ? v : 0u, scratch, &tm);
-        // block-uniform by construction; telling the compiler so keeps everything derived from them (loop bounds, the
-        // record buffer's descriptor) in scalar registers -- a descriptor it believes divergent is "waterfalled": every
-        // load wrapped in a readfirstlane loop with a full s_waitcnt, i.e. serialised
-        c_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)tm);
-        off = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
+    auto bin_extent = [&]() {  // this bin's count and offset (k_l1_scan and the scatter's block 0 wrote them): block-uniform, two scalar loads
+        // -- telling the compiler so keeps everything derived from them (loop bounds, the record buffer's descriptor) in scalar
+        // registers; a descriptor it believes divergent is "waterfalled": every load wrapped in a readfirstlane loop with a full s_waitcnt
+        c_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bin_count[bin]);
+        off = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bin_count[kBinOffsets + bin]);
         if ((uint64_t)off + c_total > a.cand_capacity) c_total = 0;  // candidate overflow (flagged by the scatter): the frame is re-run
         if (c_total > kMaxInBin) {
             if (tid == 0) atomicOr(&a.counters->overflow, 2u);

@@ -165,7 +165,7 @@ struct BinLaunch {
     uint32_t* vis_count;
     uint32_t vis_region_slots;
     uint32_t* hist;             // [padded bins + 1][bin_level1_columns(n_bound)] (the last row: visible items per block)
-    uint32_t* bin_count;        // [1024]
+    uint32_t* bin_count;        // [2048]: per padded bin its candidate count, then (from 1024 on) its offset in the candidate buffer
     uint32_t* cand;             // [cand_capacity] records (3 words each) or ids
     uint32_t* ranges;           // [T][2]
     uint32_t* sorted_gid;       // [capacity (+4)]

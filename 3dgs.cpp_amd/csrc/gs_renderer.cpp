@@ -50,7 +50,7 @@ struct FrameBuffers {
     DevBuf<uint32_t> dkeys[2], dvals[2];
     DevBuf<uint32_t> block_hist, digit_total;
     // two-level binning
-    DevBuf<uint32_t> l1_hist, bin_count;  // [padded bins][level-1 blocks], [1024]
+    DevBuf<uint32_t> l1_hist, bin_count;  // [padded bins][level-1 blocks], [1024 counts + 1024 offsets]
     DevBuf<uint32_t> cand;                // [3 x cand_capacity] bin-major candidates: 12-byte records {depth bits, id, box} on the bin-local path, plain ids otherwise
     DevBuf<uint32_t> sorted;              // [capacity + 4] per-tile lists, bin-major
     DevBuf<uint32_t> ranges;              // [T][2]
@@ -102,7 +102,7 @@ struct FrameBuffers {
         vis_region_slots = gs::vis_region_slots(static_cast<uint32_t>(n));
         if (dense_lists) ensure_dense_lists();  // only scenes of >= dense_min Gaussians ever use them (16 B x N)
         l1_hist.alloc(1025 * static_cast<size_t>(gs::bin_level1_columns(static_cast<uint32_t>(n))));  // + the row of visible counts
-        bin_count.alloc(1024);
+        bin_count.alloc(2048);  // counts, then offsets (gs_bin.h: kBinOffsets)
         counters.alloc(1);
         stamps.alloc(gs::ST_COUNT);
         HIP_CHECK(hipMemset(stamps.p, 0, gs::ST_COUNT * sizeof(uint64_t)));

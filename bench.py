@@ -237,6 +237,14 @@ def main():
     # the RUNNING MINIMUM without improving on it -- round 5 compared neighbours, which a smooth ramp satisfies: the driver's first
     # five timed batches were 5-19 % slow -- (b) the tuner has settled, (c) MIN_WARM_SECONDS have passed (every rank runs the same
     # count: decided on the max over ranks)
+    # The harness must not stall the frame loop it times: rounds 2-4 lost one 35-45 ms batch per run to Python's full garbage
+    # collection (cyclic garbage from numpy's `ctypes.data_as` in the binding, 170 000 objects to walk once torch is imported;
+    # profiles/r05_stall_hunt.txt).  The binding no longer produces garbage; what setup left behind is collected now and the
+    # survivors are moved out of the collector's sight, so nothing count-triggered can land inside the timed region.  This happens
+    # BEFORE the warm-up batches, not between them and the timed ones (round 6: the collection itself idles the GPU for tens of
+    # milliseconds, the clocks fall, and the first timed batches ran 5-20 % slow however long the warm-up had been).
+    gc.collect()
+    gc.freeze()
     best, stable, warm_batches, tuner_settled, warm_s = None, 0, 0, False, 0.0
     for _ in range(400):
         sync_all()
@@ -262,13 +270,6 @@ def main():
     sync_all()
     rend.timing_totals(reset=True)
     rend.frame_intervals(reset=True)
-    # The harness must not stall the frame loop it times: rounds 2-4 lost one 35-45 ms batch per run to Python's full garbage
-    # collection (cyclic garbage from numpy's `ctypes.data_as` in the binding, 170 000 objects to walk once torch is imported;
-    # profiles/r05_stall_hunt.txt).  The binding no longer produces garbage; what setup left behind is collected now and the
-    # survivors are moved out of the collector's sight, so nothing count-triggered can land inside the timed region.
-    gc.collect()
-    gc.freeze()
-
     def timed_batch():
         """EXACTLY K frames between barrier + synchronize on both sides; max over ranks."""
         sync_all()
