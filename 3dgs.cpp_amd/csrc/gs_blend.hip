@@ -83,9 +83,16 @@ __device__ __forceinline__ float min_q_rect(float c00, float c01, float c11, flo
     return in_x ? (in_y ? 0.0f : qh) : (in_y ? qv : fminf(qv, qh));
 }
 
-#ifdef GS_BLEND_STATS
-// debug instrumentation (separate build, never the shipped library)
+#if defined(GS_BLEND_STATS) || defined(GS_BLEND_CLOCK)
+// debug instrumentation (separate builds, never the shipped library).  GS_BLEND_STATS: the work counters (they live in the compiler's
+// form of the pair loop); GS_BLEND_CLOCK: only the shader clock the kernel ran at, measured around the SHIPPED loops
 __device__ unsigned long long g_blend_stats[12];
+// per wave of the last launch: shader cycles (s_memtime) and constant-rate ticks (s_memrealtime) between its first and its last instruction
+// -- plain stores into the wave's own slot (two atomics per wave on two addresses serialise at 12 ns each: 0.8 ms for config B's 32 640 waves)
+constexpr uint32_t kClockSlots = 1u << 18;
+__device__ uint2 g_blend_clock[kClockSlots];
+#endif
+#ifdef GS_BLEND_STATS
 #define STAT_ADD(i, v) do { const unsigned long long v_ = (unsigned long long)(v); const bool first_ = (__ffsll((unsigned long long)__ballot(true)) - 1) == lane; if (first_) atomicAdd(&g_blend_stats[i], v_); } while (0)
 #else
 #define STAT_ADD(i, v) do { } while (0)
@@ -758,6 +765,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                  const FrameParams* __restrict__ fp, uint32_t* __restrict__ vis_count, uint32_t lockstep,
                                                  uint64_t* __restrict__ stamps) {
     frame_stamp(stamps, ST_BLEND);
+#if defined(GS_BLEND_STATS) || defined(GS_BLEND_CLOCK)
+    const long long stat_c0 = clock64();                 // s_memtime: shader cycles
+    const unsigned long long stat_w0 = wall_clock64();   // s_memrealtime: the constant-rate clock
+#endif
     static_assert(!GUARD || (EXP != 2 && !CONTRACT), "the guard belongs to a fast exp on the uncontracted arithmetic");
     if (fp) {  // graph replay: this frame's targets come from the parameter block
         rgba = reinterpret_cast<float4*>(fp->rgba);
@@ -824,6 +835,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                               unused, table_ready, false);
         }
     }
+#if defined(GS_BLEND_STATS) || defined(GS_BLEND_CLOCK)
+    {   // the shader clock this kernel actually ran at: cycles and constant-rate ticks per wave, summed (tools/blend_stats.py divides)
+        const uint32_t slot = blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+        if ((threadIdx.x & (WAVE - 1)) == 0 && slot < kClockSlots)
+            g_blend_clock[slot] = make_uint2((uint32_t)(clock64() - stat_c0), (uint32_t)(wall_clock64() - stat_w0));
+    }
+#endif
     // (no __syncthreads / s_barrier from here to the end: see the header)
     if (inside) {
         const size_t p = (size_t)py * width + px;
@@ -951,12 +969,25 @@ extern "C" int gs_debug_expf_scan(int device, uint32_t first_bits, uint64_t coun
     return rc;
 }
 
-#ifdef GS_BLEND_STATS
+#if defined(GS_BLEND_STATS) || defined(GS_BLEND_CLOCK)
 extern "C" int gs_debug_blend_stats(unsigned long long* out, int reset) {
     unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_stats), sizeof z) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, sizeof z) != hipSuccess) return -1;
     return 0;
+}
+// the last launch's per-wave (cycles, ticks) of the first `waves` waves, summed: out[0] cycles, out[1] ticks
+extern "C" int gs_debug_blend_clock(unsigned long long* out, unsigned waves) {
+    if (waves > kClockSlots) waves = kClockSlots;
+    uint2* h = new uint2[waves];
+    const hipError_t e = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_blend_clock), sizeof(uint2) * waves);
+    out[0] = out[1] = 0;
+    for (unsigned i = 0; e == hipSuccess && i < waves; ++i) {
+        out[0] += h[i].x;
+        out[1] += h[i].y;
+    }
+    delete[] h;
+    return e == hipSuccess ? 0 : -1;
 }
 #endif
 
