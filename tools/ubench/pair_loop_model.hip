@@ -17,11 +17,46 @@
     "v_mul_f32 %[w], v56, %[T]\n v_mul_f32 %[T], %[T], v55\n v_cmp_gt_f32 vcc, %[k], %[T]\n v_cmp_eq_u32 vcc, %[T], %[k]\n" \
     "v_fmac_f32 %[c0], v60, %[w]\n v_fmac_f32 %[c1], v61, %[w]\n v_fmac_f32 %[c2], v62, %[w]\n"
 
+// the shipped loop's body (gs_blend.hip: GS_PAIR_GUARDED), one pair per iteration; ABL selects an ablation:
+//   0 as shipped   1 v_exp_f32 -> v_mul_f32   2 the exec-writing compare (v_cmpx) -> v_cmp   3 no scalar tail (exec / alive / rem bookkeeping)   4 no s_nop
+#define REAL_HEAD                                                                                                                  \
+    "ds_read_b128 v[54:57], %[a]\n ds_read_b128 v[58:61], %[a] offset:1024\n ds_read_b64 v[62:63], %[a] offset:2048\n s_waitcnt lgkmcnt(0)\n" \
+    "v_sub_f32 v58, v58, %[fx]\n v_sub_f32 v59, v59, %[fy]\n v_mul_f32 v54, v54, v58\n v_mul_f32 v56, v56, v59\n"                  \
+    "v_mul_f32 v54, v58, v54\n v_mul_f32 v56, v59, v56\n v_mul_f32 v55, v55, v58\n v_add_f32 v54, v54, v56\n"                       \
+    "v_mul_f32 v55, v55, v59\n v_add_f32 v54, v55, v54\n"
+template <int ABL>
+__device__ __forceinline__ void real_pair(uint32_t addr, uint64_t& alive, uint32_t& rem, float fx, float fy, float& T, float& c0, float& c1, float& c2) {
+    float w;
+    uint64_t mk;
+    const float k1e4 = 1e-4f;
+    const uint32_t slice = 0x38D1u;
+    asm volatile(REAL_HEAD
+                 "%=:\n"
+                 : : [a] "v"(addr), [fx] "v"(fx), [fy] "v"(fy) : "memory", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    if (ABL == 2) asm volatile("v_cmp_le_u32 vcc, v54, v63" ::: "vcc");
+    else asm volatile("v_cmpx_le_u32 vcc, v54, v63" ::: "vcc", "exec");
+    if (ABL == 1) asm volatile("v_mul_f32 v56, 0xbfb8aa3b, v54\n v_mul_f32 v56, v56, v56" ::: "v56");
+    else if (ABL == 4) asm volatile("v_mul_f32 v56, 0xbfb8aa3b, v54\n v_exp_f32 v56, v56\n v_mov_b32 v55, v57" ::: "v56", "v55");
+    else asm volatile("v_mul_f32 v56, 0xbfb8aa3b, v54\n v_exp_f32 v56, v56\n s_nop 0" ::: "v56");
+    asm volatile("v_mul_f32 v56, v57, v56\n v_min_f32 v56, 0x3f7d70a4, v56\n v_sub_f32 v55, 1.0, v56\n v_mul_f32 %[w], v56, %[T]\n v_mul_f32 %[T], %[T], v55\n"
+                 "v_cmp_gt_f32 %[mk], %[k1e4], %[T]\n v_cmp_eq_u32_sdwa vcc, %[T], %[slice] src0_sel:WORD_1 src1_sel:DWORD\n"
+                 : [T] "+v"(T), [w] "=&v"(w), [mk] "=&s"(mk) : [k1e4] "s"(k1e4), [slice] "s"(slice) : "vcc", "v55", "v56");
+    if (ABL == 3) {
+        asm volatile("v_fmac_f32 %[c0], v60, %[w]\n v_fmac_f32 %[c1], v61, %[w]\n v_fmac_f32 %[c2], v62, %[w]\n"
+                     : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2) : [w] "v"(w));
+    } else {
+        asm volatile("s_andn2_b64 exec, exec, %[mk]\n v_fmac_f32 %[c0], v60, %[w]\n v_fmac_f32 %[c1], v61, %[w]\n v_fmac_f32 %[c2], v62, %[w]\n"
+                     "s_andn2_b64 %[alive], %[alive], %[mk]\n s_cselect_b32 %[rem], %[rem], 0\n s_mov_b64 exec, %[alive]\n s_add_u32 %[rem], %[rem], -1\n"
+                     : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [alive] "+s"(alive), [rem] "+s"(rem) : [w] "v"(w), [mk] "s"(mk) : "scc", "exec");
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, const float* entries, int iters) {
     __shared__ float4 slab[4][3][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int p = 0; p < 3; ++p) slab[w][p][lane] = make_float4(0.001f * lane, 0.002f, 0.003f, 0.5f);
+    for (int p = 0; p < 3; ++p) slab[w][p][lane] = MODE >= 6 ? (p == 0 ? make_float4(0.001f, 0.0f, 0.001f, 0.3f) : p == 1 ? make_float4(3.5f, 3.5f, 0.5f, 0.5f) : make_float4(0.5f, 100.0f, 0.f, 0.f))
+                                                              : make_float4(0.001f * lane, 0.002f, 0.003f, 0.5f);
     __syncthreads();
     float c0 = 0, c1 = 0, c2 = 0, T = 1.0f, ww;
     const float fx = (float)(lane & 7), fy = (float)(lane >> 3), kk = 1e-4f;
@@ -75,6 +110,11 @@ __global__ __launch_bounds__(256) void k(float* out, const float* entries, int i
                          : "vcc", "memory", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s60", "s61", "s62",
                            "s63", "s64", "s65", "s66", "s67", "s68", "s69");
             e = entries + (size_t)((wu + (uint32_t)i) & 1023) * 16;
+        } else if (MODE >= 6 && MODE <= 10) {
+            uint64_t alive = ~0ull;
+            uint32_t rem = 1000;
+            real_pair<MODE - 6>(addr, alive, rem, fx, fy, T, c0, c1, c2);
+            T = T * 0.5f + 0.5f;  // (keeps T away from the thresholds: one more VALU, in every ablation alike)
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = c0 + c1 + c2 + T;
@@ -90,8 +130,10 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const char* names[] = {"23 VALU, no LDS", "23 VALU + 3 broadcast reads (shipped shape)", "3 broadcast reads alone (+1 VALU)", "23 VALU + 3 reads under exec = 16 lanes",
-                           "33 VALU (10 readfirstlane) + 16-lane reads, entry in SGPRs", "23 VALU + s_load x8 + x2 of the next entry"};
-    for (int mode = 0; mode < 6; ++mode) {
+                           "33 VALU (10 readfirstlane) + 16-lane reads, entry in SGPRs", "23 VALU + s_load x8 + x2 of the next entry",
+                           "the shipped body (+1 VALU to keep T in range)", "  ... v_exp_f32 -> v_mul_f32", "  ... v_cmpx (writes exec) -> v_cmp", "  ... without the scalar tail (exec / alive / rem)",
+                           "  ... the s_nop behind v_exp replaced by a v_mov"};
+    for (int mode = 0; mode < 11; ++mode) {
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(e0);
@@ -102,6 +144,11 @@ int main() {
                 case 3: hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, out, ent, iters); break;
                 case 4: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, ent, iters); break;
                 case 5: hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, out, ent, iters); break;
+                case 6: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, out, ent, iters); break;
+                case 7: hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(256), 0, 0, out, ent, iters); break;
+                case 8: hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(256), 0, 0, out, ent, iters); break;
+                case 9: hipLaunchKernelGGL(k<9>, dim3(blocks), dim3(256), 0, 0, out, ent, iters); break;
+                case 10: hipLaunchKernelGGL(k<10>, dim3(blocks), dim3(256), 0, 0, out, ent, iters); break;
             }
             hipEventRecord(e1);
             hipEventSynchronize(e1);
