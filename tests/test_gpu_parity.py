@@ -471,6 +471,46 @@ def test_blend_tuner_looks_again_on_the_device(pkg, gpu):
     scene.close()
 
 
+def test_spans_are_the_kernels_own_stamps(pkg, gpu, _sort_path):
+    """Round 6: the six spans of gs_frame_stats are stamped by the kernels themselves (gs_kernels.h: FrameStamp) -- a pass's span runs
+    from its first kernel's start to the next pass's, so the spans tile the frame exactly; on the global path the depth order's
+    launches are part of `sort`; gs_set_timing(0) leaves the total; and the
+    frame's total lies inside the wall clock around it (the stamps count a constant-rate clock: hipDeviceAttributeWallClockRate)."""
+    import time
+    rec = pkg.synth.synth_records(30000, seed=12, kind="A")
+    scene = pkg.Scene.from_records(rec)
+    rend = pkg.Renderer(scene)
+    w, h = 640, 360
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    hb = _HipBuffers()
+    ptr = hb.alloc(w * h * 16)
+    for _ in range(5):
+        rend.render(u, ptr)
+    rend.synchronize()
+    t0 = time.perf_counter()
+    rend.render(u, ptr)
+    rend.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    st = rend.stats()
+    spans = [st.ms_preprocess, st.ms_prefix_sum, st.ms_preprocess_sort, st.ms_sort, st.ms_render]
+    assert all(x > 0 for x in spans) and st.ms_tile_boundary == 0
+    assert abs(sum(spans) - st.ms_total) <= 1e-3 * st.ms_total + 2e-5      # they tile the frame (float32 ms of 10-ns ticks)
+    assert 0 < st.ms_total <= wall_ms * 1.05 + 0.05
+    assert st.sort_path == (1 if _sort_path == "1" else 2)
+    rend.set_timing(False)
+    rend.render(u, ptr)
+    rend.synchronize()
+    st0 = rend.stats()
+    assert st0.ms_total > 0 and st0.ms_render == 0 and st0.ms_preprocess == 0
+    rend.set_timing(True)
+    rend.render(u, ptr)
+    rend.synchronize()
+    assert rend.stats().ms_render > 0
+    hb.close()
+    rend.close()
+    scene.close()
+
+
 def test_frame_intervals_track_completions(pkg, gpu):
     """gs_get_frame_intervals: one completion-to-completion interval per consecutive pair of retired frames -- never negative
     (0 for a frame that had already finished when its predecessor did: frames on different streams complete out of order and
