@@ -298,3 +298,68 @@ def _quadrant_end_chunks(ref, w, h):
         q = first.reshape(2, 8, 2, 8).max(axis=(1, 3))
         out[2 * (t // tx):2 * (t // tx) + 2, 2 * (t % tx):2 * (t % tx) + 2] = q // 64
     return out
+
+
+def _exactly_centred_vertices(oracle, w, h, n_want=24, seed=5):
+    """Vertices whose projected centres land EXACTLY on integer pixels (dx = dy = 0 there, so render.comp:66's `power` is a zero --
+    of either sign, depending on the sign of the conic's off-diagonal term).  Found by sweeping adjacent binary32 positions through
+    the checker's preprocess until uv is an integer in both coordinates."""
+    rng = np.random.default_rng(seed)
+    tan = np.tan(np.radians(45.0) / 2)
+    found = []
+    for _ in range(400):
+        if len(found) >= n_want:
+            break
+        z = float(rng.uniform(2.5, 7.0))
+        kx, ky = int(rng.integers(8, w - 8)), int(rng.integers(8, h - 8))
+        x0 = np.float32(((2 * kx + 1) / w - 1) * tan * z)
+        y0 = np.float32(-((2 * ky + 1) / h - 1) * tan * (h / w) * z)
+        xs = (np.arange(-300, 301, dtype=np.int64) + np.int64(x0.view(np.int32))).astype(np.int32).view(np.float32)
+        ys = (np.arange(-300, 301, dtype=np.int64) + np.int64(y0.view(np.int32))).astype(np.int32).view(np.float32)
+        m = len(xs)
+        pos = np.stack([xs, ys, np.full(m, -z, np.float32)], axis=1)
+        v = _vertices(pos, np.full((m, 3), 0.05), np.full(m, 0.9, np.float32), np.full((m, 3), 0.5))
+        vv = np.ascontiguousarray(v).view(oracle.VERTEX_DT).reshape(-1)
+        attr, tiles = oracle.preprocess(vv, oracle.cov3d(vv), oracle.camera_uniforms(oracle.default_camera(), w, h))
+        ux = np.nonzero((attr["uv"][:, 0] == kx) & (tiles > 0))[0]
+        uy = np.nonzero((attr["uv"][:, 1] == ky) & (tiles > 0))[0]
+        if len(ux) and len(uy):
+            found.append((xs[ux[0]], ys[uy[0]], -z, kx, ky))
+    assert len(found) >= 8, f"only {len(found)} exactly centred positions found"
+    f = np.array(found, np.float64)
+    n = len(f)
+    # anisotropic, rotated about the view axis by angles of both signs: the conic's c01 takes both signs (and ~0)
+    ang = rng.uniform(-1.4, 1.4, n)
+    ang[:3] = 0.0
+    v = _vertices(f[:, :3].astype(np.float32), np.stack([rng.uniform(0.02, 0.08, n), rng.uniform(0.005, 0.02, n), np.full(n, 0.01)], axis=1),
+                  rng.uniform(0.3, 0.999, n).astype(np.float32), rng.uniform(0.1, 0.9, (n, 3)))
+    v[:, 8] = np.cos(ang / 2)   # rotation quaternion (w, x, y, z): about z
+    v[:, 11] = np.sin(ang / 2)
+    return v, f[:, 3].astype(int), f[:, 4].astype(int)
+
+
+def test_pixels_exactly_on_a_splats_centre(pkg, oracle, gpu):
+    """render.comp:66 at dx = dy = 0: power is +0 or -0 depending on the sign of the conic's off-diagonal term, and `power > 0` is
+    false for both, so the pixel takes alpha = min(0.99, o).  The hand-written pair loops decide :68 and :78 with ONE unsigned compare
+    on pn = -power's bit pattern, which rests on pn never being -0 (gs_blend.hip): splats whose centres sit exactly on integer pixels,
+    rotated so that c01 takes both signs, must give the reference's frame bit for bit (exp mode 2) and its decisions (default)."""
+    w, h = 320, 192
+    verts, kx, ky = _exactly_centred_vertices(oracle, w, h)
+    u_ref, ref = _reference(oracle, verts, w, h)
+    attr = ref["attr"]
+    on_centre = (attr["uv"][:, 0] == kx) & (attr["uv"][:, 1] == ky)
+    c01 = attr["conic_opacity"][:, 1]
+    assert on_centre.sum() >= 8 and (c01[on_centre] > 0).any() and (c01[on_centre] < 0).any()
+    scene = pkg.Scene.from_vertices(verts, device=0)
+    rend = pkg.Renderer(scene)
+    u = pkg.camera_uniforms(pkg.make_camera(), w, h)
+    assert u.tobytes() == u_ref.tobytes()
+    rend.set_exp_mode(2)
+    exact, _ = rend.render_host(u)
+    compare_stages(pkg, rend, u, ref)
+    assert_images_identical(exact, ref["image"], label="exactly centred splats, exp mode 2")
+    assert_guarded_close(rend, u, ref["image"], label="exactly centred splats: guarded blend")
+    # the centre pixels did take the splat: each is brighter than black
+    assert all(ref["image"][y, x, :3].sum() > 0 for x, y in zip(kx[on_centre], ky[on_centre]))
+    rend.close()
+    scene.close()
