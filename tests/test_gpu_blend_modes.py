@@ -127,3 +127,40 @@ def test_blend_lockstep_changes_no_pixel_and_the_tuner_settles(pkg, gpu):
     assert rend.blend_lockstep()[1] is True and seen == {False, True}  # both settings were tried, one was chosen
     rend.close()
     scene.close()
+
+
+def test_alternating_frame_shapes_each_get_their_own_tuner(pkg, gpu):
+    """A caller alternating two resolutions (a main view and a thumbnail) used to restart the one blend tuner on every frame and never
+    settled (round-5 advisor finding).  Each frame shape has its own tuner now (gs_blend_tuner.h: BlendTunerBank): both settle, and every
+    frame on the way is the frame of a fresh renderer with the schedule pinned."""
+    import ctypes
+    rec = pkg.synth.synth_records(40_000, seed=9, kind="T")
+    scene = pkg.Scene.from_records(rec, device=0)
+    shapes = [(640, 360), (320, 192)]
+    us = [pkg.camera_uniforms(pkg.make_camera(), w, h) for w, h in shapes]
+    want = []
+    pinned = pkg.Renderer(scene)
+    pinned.set_exp_mode(3)
+    pinned.set_blend_lockstep(0)
+    for u in us:
+        want.append(pinned.render_host(u)[0])
+    pinned.close()
+    rend = pkg.Renderer(scene)
+    rend.set_exp_mode(3)
+    rend.set_blend_lockstep(-1)
+    rend.set_frames_in_flight(2)
+    settled = [False, False]
+    for k in range(2 * 420):  # (40 frames of hold + at most two passes of ~70 per shape, interleaved)
+        i = k & 1
+        img = rend.render_host(us[i])[0]
+        assert np.array_equal(img.view(np.uint32), want[i].view(np.uint32)), (k, i)
+        settled[i] = rend.blend_lockstep()[1]   # (the shape of the most recently enqueued frame)
+        if all(settled):
+            break
+    assert all(settled), settled
+    # ... and they stay settled when the shapes keep alternating
+    for k in range(20):
+        rend.render_host(us[k & 1])
+        assert rend.blend_lockstep()[1] is True
+    rend.close()
+    scene.close()
