@@ -206,12 +206,13 @@ __device__ __forceinline__ bool resolve_break(const uint32_t* __restrict__ klist
 // one scalar unit is a co-bottleneck.  Most of those scalar instructions move lane masks between VCC,
 // SGPR pairs and exec: `alive & ballot & ballot`, "is any lane left", save / restore exec around the accumulate, "did the last
 // pixel die".  This loop keeps ALIVE IN EXEC for its whole life instead:
-//   * the two tests of render.comp:68,78 are v_cmpx (exec &= condition): exec IS m2, "no lane" is one s_cbranch_execz;
+//   * the tests of render.comp:68,78 are v_cmpx (exec &= condition; round 5: two float compares, round 6: ONE unsigned compare, below): exec IS m2;
 //   * under exec = m2 the break compare yields mk and the slice compare (into VCC: one s_cbranch_vccnz) yields sl directly;
 //   * T <- T (1 - alpha) is written in place for every lane of m2 -- a lane that breaks here is dead from here on, its T is never
 //     read again -- after the weight alpha T was formed from the old T; the accumulate runs under exec = m2 & ~mk (one s_andn2);
 //   * the wave's kept entries are staged COMPACTED (rank order), so the loop walks an address and a count: no s_ff1 / s_bitset0.
-// 25 vector + 7 scalar instructions per pair on the common path, two branches (the event test and the back edge).  Same arithmetic, operation for operation, as the loop it
+// Round 5: 25 vector + 7 scalar instructions per pair on the common path, two branches (the event test and the back edge); round 6: 23.25 + 7 and
+// 1.25 taken branches (below).  Same arithmetic, operation for operation, as the loop it
 // replaces (every product and sum of render.comp:66 rounded on its own, v_exp_f32, fl(o e), min, 1 - alpha, T (1 - alpha), the
 // fused accumulate of the guarded mode): the images of the two loops are bit-identical (tools/ab_image_check.py).
 // The loop returns to C++ (event = 1) only where the guard needs it: a lane of m2 inside the guard's COARSE window around 1e-4 (the
