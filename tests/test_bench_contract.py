@@ -190,3 +190,24 @@ def test_committed_counters_belong_to_the_library_as_built(pkg):
     assert r["counters"] == c["file"] and v["peak"] == 1228.8
     assert abs(v["frac"] - c["valu_wave_insts"] / 0.30e-3 / m.VALU_PEAK) < 1e-3          # per frame time
     assert abs(v["one_in_flight_frac"] - c["valu_wave_insts"] / 0.24e-3 / m.VALU_PEAK) < 1e-3
+
+
+def test_rocprof_summary_agrees_with_the_bench_line():
+    """The contract: `roofline.achieved` comes from the dominant kernel's launch duration measured live inside bench.py, and the committed
+    `rocprofv3 --kernel-trace --stats` summary's average for that kernel must agree.  The live figure is the kernels' own stamps (blend start
+    to frame end); the summary is profiles/r06_kernel_stats_B_serial.txt (one frame at a time, the same library)."""
+    import re
+    with open(os.path.join(ROOT, "profiles", "r06_bench_default.json")) as f:
+        b = json.load(f)
+    r = b["roofline"]
+    live_ms = r["one_in_flight"]["ms"]
+    avg_us = None
+    with open(os.path.join(ROOT, "profiles", "r06_kernel_stats_B_serial.txt")) as f:
+        for line in f:
+            if line.startswith(r["kernel"]):
+                avg_us = float(re.split(r"\s{2,}", line.strip())[3])
+    assert avg_us is not None, r["kernel"]
+    assert abs(live_ms * 1e3 - avg_us) / avg_us < 0.03, (live_ms, avg_us)
+    # ... and the flop view follows from that duration and the committed pair count alone
+    assert abs(r["one_in_flight"]["frac"] - 22 * r["walked_pairs"] / (live_ms * 1e-3) / 157.3e12) < 2e-3
+    assert abs(b["passes_serial_ms"]["render"] - live_ms) < 1e-3
